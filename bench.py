@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- dequant GB/s (packed in -> fp16 out) and % of HBM3E peak, per quant type.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--qtype Q4_K] [--pairs 8]
+
+A "step" is ONE pass of the hot path over the whole synthetic pool: a DequantPlan launch
+(include/ggq.h ggq_plan_launch) over `pairs` x (3072x3072 + 3072x12288) FLUX.1-dev-shaped
+linears of one quant type -- 0.97 GB of traffic per step for Q4_K, far beyond the 256 MiB
+Infinity Cache, every tensor with its own packed and output buffers.  Packed inputs are resident
+in HBM before the timed region starts.
+
+Headline workload: Q4_K (the north-star target format, BASELINE.json configs[2]); configs[1]
+(Q4_0) and every other format are measured the same way and reported under "per_qtype".
+
+Multi-GPU (driver: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...):
+one process per GPU, WEAK scaling -- the global tensor list is N pools, partitioned by
+comfyui-gguf_amd/sharding.py; no collective on the data path.  torch.distributed (RCCL) only
+fences the timed region (barrier) and takes the MAX time over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ggq_pkg import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:35
+
+
+def global_manifest(pkg, qtype, pairs, world):
+    """Weak scaling: the job's tensor list is `world` copies of the per-GPU pool."""
+    m = []
+    for r in range(world):
+        m += [(f"gpu{r}.{name}", q, shape) for name, q, shape in pkg.manifests.flux_linear_pool(qtype, pairs)]
+    return m
+
+
+def max_over_ranks(value, device):
+    """MAX of a python float over all ranks (identity when not distributed)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def device_blocks(pkg, qtype, n_blocks, device, seed):
+    """Random packed blocks generated ON the device, scale fields overwritten with nominal fp16
+    values (same distribution as comfyui-gguf_amd/synth.py mode 'nominal')."""
+    qt = pkg.qtypes
+    _, ts = qt.block_geometry(qtype)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    blocks = torch.randint(0, 256, (n_blocks, ts), dtype=torch.uint8, device=device, generator=g)
+    lo, hi = (1e-3, 2.1e-2) if qtype in qt.LEGACY_QTYPES else (1e-4, 2e-3)
+    for off in qt.SCALE_FIELDS[qtype]:
+        vals = (torch.rand(n_blocks, device=device, generator=g) * (hi - lo) + lo).to(torch.float16)
+        blocks[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
+    return blocks.reshape(-1)
+
+
+def build_pool(pkg, entries, device, seed0):
+    items = []
+    for i, (_, q, shape) in enumerate(entries):
+        n_blocks = pkg.synth.n_blocks_for(q, shape[0] * shape[1])
+        items.append((device_blocks(pkg, q, n_blocks, device, seed0 + i), q, shape))
+    return pkg.grouped.DequantPlan(items, out_dtype=torch.float16)
+
+
+def timed_steps(plan, steps, warmup, device, fence):
+    """W untimed + exactly K timed launches, HIP events on the stream the kernels run on."""
+    stream = torch.cuda.current_stream(device)
+    for _ in range(warmup):
+        plan.launch(stream)
+    fence()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    start.record(stream)
+    for _ in range(steps):
+        plan.launch(stream)
+    stop.record(stream)
+    torch.cuda.synchronize(device)
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    fence()
+    return start.elapsed_time(stop), wall_ms
+
+
+def cpu_baseline(pkg, plan, qtype, budget_s):
+    """The CPU oracle (oracle/ggq_oracle.c, kind 'port' of the reference's torch-CPU path) timed on
+    this box's host cores on a bounded sample of the same workload: the first tensor of the pool
+    (same packed bytes, copied back from the GPU), repeated for ~budget_s seconds.  Also re-checks
+    parity: the GPU output of that tensor must equal the oracle's bit for bit."""
+    import numpy as np
+    import oracle
+    data, out = plan._keep[0], plan.outputs[0]
+    packed = data.cpu().numpy()
+    max_threads = int(oracle.lib().ggq_oracle_max_threads())
+    want = oracle.dequant_f16(qtype, packed)          # warm-up + parity
+    got = out.cpu().numpy().reshape(-1)
+    parity = bool(np.array_equal(got.view(np.uint16), want.view(np.uint16)))
+    nbytes = pkg.qtypes.algorithmic_bytes(qtype, out.numel())
+    # OpenMP on every hardware thread of a shared box is not the fastest setting (spin-waiting
+    # threads fight over cores): try a few team sizes, report the best median and ITS thread count.
+    counts = sorted({c for c in (1, 8, 16, 32, 64, max_threads) if c <= max_threads})
+    best = None
+    for c in counts:
+        times = []
+        t_end = time.perf_counter() + budget_s / len(counts)
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
+            t0 = time.perf_counter()
+            oracle.dequant_f16(qtype, packed, threads=c)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        if best is None or med < best[0]:
+            best = (med, c, len(times), times[0])
+    med, threads, reps, tmin = best
+    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": (f"{qtype.name} {tuple(out.shape)[0]}x{tuple(out.shape)[1]} (first pool tensor, same packed bytes), "
+                       f"{reps} reps of oracle/ggq_oracle.c with OpenMP on {threads} threads (best of team sizes {counts}; "
+                       f"{os.cpu_count()} host CPUs visible), median; fastest rep {nbytes / tmin / 1e9:.3f} GB/s"),
+            "parity_vs_gpu": "bit-exact" if parity else "MISMATCH"}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from the committed PMC summary (collected in separate rocprofv3 --pmc
+    passes and corrected per MI355X_MICROARCH.md; see profiles/README.md), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload_key)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--qtype", default="Q4_K", help="headline quant type (default: the north-star target Q4_K)")
+    ap.add_argument("--pairs", type=int, default=8, help="(3072x3072 + 3072x12288) pairs in the per-GPU pool")
+    ap.add_argument("--no-per-qtype", action="store_true", help="skip the per-format table")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
+        sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL: fence + MAX only
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    pkg = load_package()
+    pkg._native.lib()                       # fail loudly if the HIP extension is missing
+    qt = pkg.qtypes
+    head_q = qt.Q[args.qtype]
+
+    manifest = global_manifest(pkg, head_q, args.pairs, world)
+    mine = pkg.sharding.shard(manifest, rank, world)
+    plan = build_pool(pkg, mine, device, seed0=1000 * rank)
+    bytes_rank = plan.bytes
+    assert plan.kernels == 1
+
+    gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup, device, fence)
+    ms_per_step = max_over_ranks(gpu_ms / args.steps, device)
+    total_bytes = bytes_rank * world                                       # identical pools on every rank
+    value = total_bytes / (ms_per_step * 1e-3) / 1e9
+
+    result = None
+    if rank == 0:
+        achieved = bytes_rank / (gpu_ms / args.steps * 1e-3) / 1e9        # rank 0's own kernel
+        n_el = sum(s[0] * s[1] for _, _, s in mine)
+        wl = f"BASELINE configs[2] {head_q.name}: FLUX.1-dev linear shapes, {args.pairs} x (3072x3072 + 3072x12288) per GPU"
+        traffic = load_traffic(f"{head_q.name}:pairs{args.pairs}")
+        result = {
+            "metric": "dequant GB/s (packed in -> fp16 out), (in+out) bytes / time",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": wl, "qtype": head_q.name, "elements_per_gpu": n_el, "bytes_per_step_per_gpu": bytes_rank,
+                       "tensors_per_gpu": len(mine), "parallelism": f"tensor-list sharding x{world}, no collectives",
+                       "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": f"ggq::dequant_many<Fmt{head_q.name}, ...>", "algorithmic_bytes_per_launch": bytes_rank,
+                         "avg_launch_ms": round(gpu_ms / args.steps, 5), "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
+        }
+    plan_head = plan
+
+    per_qtype = {}
+    if not args.no_per_qtype and rank == 0 and world == 1:
+        steps_q = max(10, args.steps // 2)
+        for q in qt.HIP_QTYPES:
+            if q == head_q:
+                per_qtype[q.name] = {"GB/s": result["roofline"]["achieved"], "pct_hbm_peak": round(100 * result["roofline"]["frac"], 2)}
+                continue
+            p = build_pool(pkg, pkg.manifests.flux_linear_pool(q, args.pairs), device, seed0=50_000 + 100 * int(q))
+            ms, _ = timed_steps(p, steps_q, 3, device, lambda: torch.cuda.synchronize(device))
+            gbs = p.bytes / (ms / steps_q * 1e-3) / 1e9
+            per_qtype[q.name] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2)}
+            p.close()
+            del p
+            torch.cuda.empty_cache()
+        result["per_qtype"] = per_qtype
+
+    if rank == 0:
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(pkg, plan_head, head_q, args.cpu_seconds)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    plan_head.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

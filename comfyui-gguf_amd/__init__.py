@@ -4,8 +4,25 @@ Scope: the one hot path of city96/ComfyUI-GGUF -- ``dequant.py`` (packed GGUF bl
 fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
 (``include/ggq.h``), with a Python host side that mirrors the reference's
 ``dequantize_tensor`` / ``dequantize`` / ``dequantize_functions`` surface.
+
+    dequant     the mirrored reference interface (HIP-backed; raises GGQUnsupported otherwise)
+    install     patch an unmodified ComfyUI-GGUF checkout so its nodes run on this path
+    grouped     DequantPlan: a whole weight set in one launch per quant type
+    sharding    tensor-list partitioning for one-process-per-GPU runs (no collectives)
+    ops         GGMLTensor / GGMLLinear stand-ins for driving the path without ComfyUI
+    manifests   synthetic weight manifests of the BASELINE.json configurations
+    synth       seeded synthetic packed blocks
+    qtypes      ggml type ids and block geometry
 """
-from . import qtypes, synth  # noqa: F401
+from . import qtypes, synth  # noqa: F401  (torch-free)
 from .qtypes import GGMLQuantizationType, GGML_QUANT_SIZES  # noqa: F401
 
 __version__ = "0.1.0"
+_LAZY = ("_native", "dequant", "install", "grouped", "sharding", "ops", "manifests")
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        return importlib.import_module(f"{__name__}.{name}")
+    raise AttributeError(name)

@@ -1,0 +1,142 @@
+"""ctypes binding of libggq_hip.so (C ABI: include/ggq.h) and its in-tree build.
+
+The shared library is built IN-TREE (``comfyui-gguf_amd/_lib/libggq_hip.so``) with hipcc for
+gfx950 so that it travels with the repository snapshot to the GPU box.  There is no fallback of
+any kind: if the library is missing or fails to load, :func:`lib` raises -- the HIP path is the
+product, a silent detour through torch or the CPU would void every parity and performance claim.
+"""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libggq_hip.so")
+SOURCES = [os.path.join(CSRC, "ggq_capi.hip")]
+HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(ROOT, "include", "ggq.h")]
+ABI_VERSION = 1
+
+# -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
+# rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+# fused multiply-add mnemonics that must not appear in the dequant kernels
+_FMA_RE = re.compile(r"\b(v_(?:pk_)?(?:fma|fmac)_\w+|v_mad_(?:f16|f32|legacy_f\w+|mix\w*|mixlo\w*|mixhi\w*)\w*)")
+
+GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM = range(6)
+OUT_F16, OUT_BF16, OUT_F32 = 0, 1, 2
+
+# every symbol include/ggq.h declares: name -> (restype, argtypes)
+_u64, _u32, _int, _vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
+
+
+class ggq_desc(ctypes.Structure):
+    _fields_ = [("qtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("packed", _vp), ("out", _vp), ("n_blocks", _u64)]
+
+
+SYMBOLS = {
+    "ggq_supported": (_int, [_int]),
+    "ggq_block_size": (_int, [_int]),
+    "ggq_type_size": (_int, [_int]),
+    "ggq_strerror": (ctypes.c_char_p, [_int]),
+    "ggq_last_hip_error": (_int, []),
+    "ggq_abi_version": (_int, []),
+    "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _vp]),
+    "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
+    "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),
+    "ggq_plan_launch": (_int, [_vp, _vp]),
+    "ggq_plan_bytes": (_u64, [_vp]),
+    "ggq_plan_kernels": (_u32, [_vp]),
+    "ggq_plan_destroy": (None, [_vp]),
+}
+
+_lib = None
+
+
+class GGQNativeError(RuntimeError):
+    """libggq_hip.so is missing / unloadable / returned a failing status."""
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def check_no_fma(asm_text):
+    """Raise if a fused multiply-add made it into the device code (build-time parity guard)."""
+    hits = sorted(set(m.group(1) for m in _FMA_RE.finditer(asm_text)))
+    if hits:
+        raise GGQNativeError(f"fused multiply-add instructions in the dequant kernels: {hits}; "
+                             "the reference rounds after every op -- build with -ffp-contract=off")
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 into comfyui-gguf_amd/_lib/ (cross-compiles without a GPU)."""
+    global _lib
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="ggq_build_") as tmp:
+        out = os.path.join(tmp, "libggq_hip.so")
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-save-temps=obj", "-o", out] + SOURCES
+        proc = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        if verbose or proc.returncode:
+            print(" ".join(cmd))
+            print(proc.stdout + proc.stderr)
+        if proc.returncode:
+            raise GGQNativeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "amdgcn" in f]
+        if not asm:
+            raise GGQNativeError("build produced no gfx950 assembly to check for FMA contraction")
+        for f in asm:
+            with open(os.path.join(tmp, f)) as fh:
+                check_no_fma(fh.read())
+        shutil.copyfile(out, LIB_PATH + ".tmp")
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    _lib = None
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises GGQNativeError if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GGQNativeError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
+                "There is no CPU or torch fallback for this path.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise GGQNativeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise GGQNativeError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+            fn.restype, fn.argtypes = res, args
+        if L.ggq_abi_version() != ABI_VERSION:
+            raise GGQNativeError(f"{LIB_PATH} has ABI {L.ggq_abi_version()}, expected {ABI_VERSION}: rebuild")
+        _lib = L
+    return _lib
+
+
+def check(status, what="ggq call"):
+    if status != GGQ_OK:
+        L = lib()
+        msg = L.ggq_strerror(status).decode()
+        if status == GGQ_ERR_HIP:
+            msg += f" (hipError_t {L.ggq_last_hip_error()})"
+        raise GGQNativeError(f"{what} failed: {msg}")

@@ -1,0 +1,226 @@
+// ggq_capi.hip -- the C ABI of include/ggq.h over the kernels of ggq_device.hpp.
+// Host side is plain C++ on the HIP runtime; nothing here knows about torch.
+#include "ggq_device.hpp"
+#include "../../include/ggq.h"
+
+#include <new>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+using namespace ggq;
+
+// Launch geometry chosen on MI355X (DESIGN.md "Tuning", profiles/r01_microbench_*): one group of
+// G blocks per wavefront, non-temporal loads and stores (the packed bytes are read once and the
+// dense tensor is not re-read by this kernel), 4 waves per workgroup.
+template <class F> struct Tune {
+    static constexpr int G = (F::BS == 256) ? 8 : 64;   // 2048 output elements = 4 KiB fp16 per group
+    static constexpr bool NTL = true, NTS = true;
+    static constexpr int WAVES = 4;
+};
+
+thread_local int t_last_hip = 0;
+constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
+
+typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
+typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, hipStream_t);
+
+template <class F, int OUT>
+hipError_t run_one(const Desc& d, hipStream_t s)
+{
+    using T = Tune<F>;
+    const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
+    if (groups == 0) return hipSuccess;
+    const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
+    if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
+    return hipGetLastError();
+}
+
+template <class F, int OUT>
+hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t s)
+{
+    using T = Tune<F>;
+    if (groups == 0) return hipSuccess;
+    const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
+    if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
+    return hipGetLastError();
+}
+
+struct FormatEntry {
+    int qtype, block_size, type_size, group;
+    one_fn one[3];
+    many_fn many[3];
+};
+
+#define GGQ_FORMAT(F)                                                                          \
+    FormatEntry {                                                                              \
+        F::ID, F::BS, F::TS, Tune<F>::G,                                                       \
+        {run_one<F, OUT_F16>, run_one<F, OUT_BF16>, run_one<F, OUT_F32>},                      \
+        {run_many<F, OUT_F16>, run_many<F, OUT_BF16>, run_many<F, OUT_F32>}                    \
+    }
+
+const FormatEntry FORMATS[] = {
+    GGQ_FORMAT(FmtQ4_0), GGQ_FORMAT(FmtQ4_1), GGQ_FORMAT(FmtQ5_0), GGQ_FORMAT(FmtQ5_1), GGQ_FORMAT(FmtQ8_0),
+    GGQ_FORMAT(FmtQ2_K), GGQ_FORMAT(FmtQ3_K), GGQ_FORMAT(FmtQ4_K), GGQ_FORMAT(FmtQ5_K), GGQ_FORMAT(FmtQ6_K),
+    GGQ_FORMAT(FmtIQ4_NL), GGQ_FORMAT(FmtIQ4_XS),
+};
+constexpr int N_FORMATS = (int)(sizeof(FORMATS) / sizeof(FORMATS[0]));
+
+const FormatEntry* find_format(int qtype)
+{
+    for (int i = 0; i < N_FORMATS; i++)
+        if (FORMATS[i].qtype == qtype) return &FORMATS[i];
+    return nullptr;
+}
+
+int hip_fail(hipError_t e)
+{
+    t_last_hip = (int)e;
+    return GGQ_ERR_HIP;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_tensor(const FormatEntry* f, const void* packed, const void* out, uint64_t n_blocks, int out_dtype)
+{
+    if (!f) return GGQ_ERR_QTYPE;
+    if (out_dtype < 0 || out_dtype > 2) return GGQ_ERR_ARG;
+    if (n_blocks == 0) return GGQ_OK;
+    if (!packed || !out) return GGQ_ERR_ARG;
+    if (!aligned16(packed) || !aligned16(out)) return GGQ_ERR_ALIGN;
+    return GGQ_OK;
+}
+
+struct Segment {
+    const FormatEntry* fmt;
+    int out_dtype;
+    uint32_t first, count;     // slice of the device table
+    uint64_t groups;
+};
+
+}  // namespace
+
+struct ggq_plan {
+    std::vector<Segment> segments;
+    Desc* dev_table = nullptr;
+    uint64_t bytes = 0;
+    int device = 0;
+};
+
+extern "C" {
+
+int ggq_abi_version(void) { return 1; }
+
+int ggq_supported(int qtype) { return find_format(qtype) ? 1 : 0; }
+
+int ggq_block_size(int qtype)
+{
+    const FormatEntry* f = find_format(qtype);
+    return f ? f->block_size : 0;
+}
+
+int ggq_type_size(int qtype)
+{
+    const FormatEntry* f = find_format(qtype);
+    return f ? f->type_size : 0;
+}
+
+const char* ggq_strerror(int status)
+{
+    switch (status) {
+    case GGQ_OK: return "ok";
+    case GGQ_ERR_QTYPE: return "quantization type has no HIP unpacker";
+    case GGQ_ERR_ALIGN: return "packed/out pointer is not 16-byte aligned";
+    case GGQ_ERR_ARG: return "invalid argument";
+    case GGQ_ERR_HIP: return "HIP runtime error (see ggq_last_hip_error)";
+    case GGQ_ERR_NOMEM: return "out of memory building a plan";
+    default: return "unknown ggq status";
+    }
+}
+
+int ggq_last_hip_error(void) { return t_last_hip; }
+
+int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int out_dtype, void* hip_stream)
+{
+    const FormatEntry* f = find_format(qtype);
+    const int rc = check_tensor(f, packed, out, n_blocks, out_dtype);
+    if (rc != GGQ_OK || n_blocks == 0) return rc;
+    const Desc d{static_cast<const uint8_t*>(packed), static_cast<uint8_t*>(out), n_blocks, 0};
+    const hipError_t e = f->one[out_dtype](d, static_cast<hipStream_t>(hip_stream));
+    return e == hipSuccess ? GGQ_OK : hip_fail(e);
+}
+
+int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream)
+{
+    return ggq_dequant(qtype, packed, n_blocks, out_f16, GGQ_OUT_F16, hip_stream);
+}
+
+int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
+{
+    if (!plan_out || (n > 0 && !descs)) return GGQ_ERR_ARG;
+    *plan_out = nullptr;
+    for (uint32_t i = 0; i < n; i++) {
+        const int rc = check_tensor(find_format(descs[i].qtype), descs[i].packed, descs[i].out, descs[i].n_blocks, descs[i].out_dtype);
+        if (rc != GGQ_OK) return rc;
+    }
+    ggq_plan* plan = new (std::nothrow) ggq_plan();
+    if (!plan) return GGQ_ERR_NOMEM;
+    std::vector<Desc> table;
+    try {
+        table.reserve(n);
+        for (int fi = 0; fi < N_FORMATS; fi++) {
+            for (int od = 0; od < 3; od++) {
+                Segment seg{&FORMATS[fi], od, (uint32_t)table.size(), 0, 0};
+                for (uint32_t i = 0; i < n; i++) {
+                    const ggq_desc& d = descs[i];
+                    if (d.qtype != FORMATS[fi].qtype || d.out_dtype != od || d.n_blocks == 0) continue;
+                    table.push_back(Desc{static_cast<const uint8_t*>(d.packed), static_cast<uint8_t*>(d.out), d.n_blocks, seg.groups});
+                    seg.groups += (d.n_blocks + FORMATS[fi].group - 1) / FORMATS[fi].group;
+                    seg.count++;
+                    plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_OUT_F32 ? 4 : 2));
+                }
+                if (seg.count) plan->segments.push_back(seg);
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        delete plan;
+        return GGQ_ERR_NOMEM;
+    }
+    (void)hipGetDevice(&plan->device);
+    if (!table.empty()) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&plan->dev_table), table.size() * sizeof(Desc));
+        if (e == hipSuccess) e = hipMemcpy(plan->dev_table, table.data(), table.size() * sizeof(Desc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (plan->dev_table) (void)hipFree(plan->dev_table);
+            delete plan;
+            return e == hipErrorOutOfMemory ? GGQ_ERR_NOMEM : hip_fail(e);
+        }
+    }
+    *plan_out = plan;
+    return GGQ_OK;
+}
+
+int ggq_plan_launch(const ggq_plan* plan, void* hip_stream)
+{
+    if (!plan) return GGQ_ERR_ARG;
+    for (const Segment& seg : plan->segments) {
+        const hipError_t e = seg.fmt->many[seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, static_cast<hipStream_t>(hip_stream));
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    return GGQ_OK;
+}
+
+uint64_t ggq_plan_bytes(const ggq_plan* plan) { return plan ? plan->bytes : 0; }
+uint32_t ggq_plan_kernels(const ggq_plan* plan) { return plan ? (uint32_t)plan->segments.size() : 0; }
+
+void ggq_plan_destroy(ggq_plan* plan)
+{
+    if (!plan) return;
+    if (plan->dev_table) (void)hipFree(plan->dev_table);
+    delete plan;
+}
+
+}  // extern "C"

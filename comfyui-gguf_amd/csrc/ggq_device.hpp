@@ -1,0 +1,504 @@
+// ggq_device.hpp -- gfx950 (MI355X / CDNA4) device code for GGUF block dequantization.
+//
+// What it computes: the reference's block unpackers (city96/ComfyUI-GGUF dequant.py:65-285),
+// bit-exactly, for the default fp16 arithmetic mode (dequant_dtype=None, nodes.py:152-153):
+// every `*`, `+`, `-` of the reference is ONE fp16 op with ONE rounding here too
+// (v_pk_mul_f16 / v_pk_add_f16; the build uses -ffp-contract=off so that d*q - dm never
+// becomes a v_pk_fma_f16 -- a fused op differs from the reference by up to 1328 ULP on Q4_K,
+// SURVEY.md section 0 finding 3).
+//
+// Shape of the work (HBM-bound byte unpack, no MFMA -- there is no contraction here):
+//   * unit of work = a GROUP of G consecutive blocks, owned by ONE wavefront (64 lanes);
+//   * the wave copies the group's packed bytes HBM -> VGPR -> its private LDS slice with
+//     coalesced 16 B/lane loads (a group starts 16-B aligned because 8*type_size % 16 == 0
+//     for every ggml block format);
+//   * every lane then produces CHUNKS of 8 consecutive output elements: it picks the quant
+//     bytes / scale fields it needs out of LDS (broadcast reads, natural alignment only),
+//     widens sub-byte fields with v_perm_b32 + the 0x6400 "1024+q" fp16 trick, applies the
+//     reference's rounding sequence in packed fp16, and issues ONE 16-byte store;
+//   * lane l of store s writes chunk 64*s + l, so each store instruction of the wave covers
+//     1 KiB of contiguous output (full 128-B lines, no partial-line writes);
+//   * waves never synchronise with each other (no __syncthreads, no atomics): LDS slices are
+//     wave-private, ordering inside a wave is in-order LDS issue + a compiler fence.
+//
+// No CUDA compatibility layer, no dual paths: this file is gfx950 code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ggq {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GGQ_DEV __device__ __forceinline__
+
+GGQ_DEV h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
+GGQ_DEV uint32_t as_u32(h2 h) { return __builtin_bit_cast(uint32_t, h); }
+GGQ_DEV h2 splat(_Float16 x) { return h2{x, x}; }
+GGQ_DEV h2 splatf(float x) { return h2{(_Float16)x, (_Float16)x}; }
+GGQ_DEV h2 bcast_lo(h2 v) { return __builtin_shufflevector(v, v, 0, 0); }
+GGQ_DEV h2 bcast_hi(h2 v) { return __builtin_shufflevector(v, v, 1, 1); }
+
+// fp16 1024.0 in both halves: (MAGIC | q) read as fp16 is exactly 1024 + q for 0 <= q < 1024,
+// and (1024 + q) - (1024 + bias) is an exact fp16 subtraction -> int -> fp16 without v_cvt.
+constexpr uint32_t MAGIC = 0x64006400u;
+
+// bytes (b0,b1) of w -> 16-bit lanes [b0, b1]; bytes (b2,b3) -> [b2, b3]   (v_perm_b32)
+GGQ_DEV uint32_t spread_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C010C00u); }
+GGQ_DEV uint32_t spread_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C030C02u); }
+
+// two small unsigned ints (bits 0.. and 16..) -> h2 of (q - bias), exact
+GGQ_DEV h2 ints_h2(uint32_t pair, float bias) { return as_h2(pair | MAGIC) - splatf(1024.0f + bias); }
+
+// ---- LDS reads at the natural alignment the block layout guarantees (a misaligned ds_read_b64
+// replays at 64 cycles, cdna_hip_programming.md Guideline 17, so 2-B-aligned formats read u16s)
+GGQ_DEV uint32_t lds_u8(const uint8_t* p) { return *p; }
+GGQ_DEV uint32_t lds_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
+GGQ_DEV _Float16 lds_h(const uint8_t* p) { return __builtin_bit_cast(_Float16, *reinterpret_cast<const uint16_t*>(p)); }
+
+template <int ALIGN>
+GGQ_DEV uint32_t lds_ld4(const uint8_t* p)
+{
+    if constexpr (ALIGN >= 4) return *reinterpret_cast<const uint32_t*>(p);
+    else return lds_u16(p) | (lds_u16(p + 2) << 16);
+}
+
+template <int ALIGN>
+GGQ_DEV u32x2 lds_ld8(const uint8_t* p)
+{
+    if constexpr (ALIGN >= 8) return *reinterpret_cast<const u32x2*>(p);
+    else return u32x2{lds_ld4<ALIGN>(p), lds_ld4<ALIGN>(p + 4)};
+}
+
+// 4 byte-fields t (one per byte, value < 1024 after OR-ing `extra`) -> two h2 of (field - bias)
+struct H2x2 { h2 a, b; };
+GGQ_DEV H2x2 fields_h2(uint32_t t, float bias)
+{
+    return H2x2{ints_h2(spread_lo(t), bias), ints_h2(spread_hi(t), bias)};
+}
+
+// 4 bits of x (bit k -> bit 0 of byte k)
+GGQ_DEV uint32_t bits4_to_bytes(uint32_t x) { return ((x & 15u) * 0x00204081u) & 0x01010101u; }
+
+// ============================================================================ block formats
+// Each format: BS elements / TS bytes per block, and
+//   chunk(b, j): the 8 output elements [8j, 8j+8) of the block whose bytes start at LDS pointer b,
+//                as 4 x (2 x fp16) bit patterns.
+
+#define GGQ_EMIT4(EXPR_A0, EXPR_B0, EXPR_A1, EXPR_B1) \
+    u32x4 { as_u32(EXPR_A0), as_u32(EXPR_B0), as_u32(EXPR_A1), as_u32(EXPR_B1) }
+
+// dequant.py:65-69    [d f16][qs i8 x32]            out = rn(d * qs)
+struct FmtQ8_0 {
+    static constexpr int ID = 8, BS = 32, TS = 34, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 d = splat(lds_h(b));
+        const u32x2 w = lds_ld8<2>(b + 2 + 8 * j);
+        // int8 x -> (x ^ 0x80) = x + 128 unsigned; 1024 + 128 + x - 1152 = x
+        const H2x2 q0 = fields_h2(w.x ^ 0x80808080u, 128.0f), q1 = fields_h2(w.y ^ 0x80808080u, 128.0f);
+        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+    }
+};
+
+// the 8 nibbles feeding chunk j of a 32-element legacy block whose 16 quant bytes start at qs:
+// j = 0,1 -> low nibbles of qs[8j..], j = 2,3 -> high nibbles of qs[8(j-2)..]    (dequant.py:121-122)
+template <int ALIGN>
+GGQ_DEV u32x2 legacy_nibbles(const uint8_t* qs, int j)
+{
+    const u32x2 w = lds_ld8<ALIGN>(qs + 8 * (j & 1));
+    const int sh = (j >> 1) * 4;
+    return u32x2{(w.x >> sh) & 0x0F0F0F0Fu, (w.y >> sh) & 0x0F0F0F0Fu};
+}
+
+// dequant.py:115-123  [d][qs u8 x16]                out = rn(d * (q - 8))
+struct FmtQ4_0 {
+    static constexpr int ID = 2, BS = 32, TS = 18, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 d = splat(lds_h(b));
+        const u32x2 t = legacy_nibbles<2>(b + 2, j);
+        const H2x2 q0 = fields_h2(t.x, 8.0f), q1 = fields_h2(t.y, 8.0f);
+        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+    }
+};
+
+// dequant.py:103-113  [d][m][qs x16]                out = rn(rn(d * q) + m)
+struct FmtQ4_1 {
+    static constexpr int ID = 3, BS = 32, TS = 20, LDS_ALIGN = 4;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 dm = as_h2(lds_ld4<4>(b));
+        const h2 d = bcast_lo(dm), m = bcast_hi(dm);
+        const u32x2 t = legacy_nibbles<4>(b + 4, j);
+        const H2x2 q0 = fields_h2(t.x, 0.0f), q1 = fields_h2(t.y, 0.0f);
+        return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
+    }
+};
+
+// dequant.py:87-101   [d][qh u32][qs x16]           q = nib | bit(qh, e) << 4;  out = rn(d * (q - 16))
+struct FmtQ5_0 {
+    static constexpr int ID = 6, BS = 32, TS = 22, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 d = splat(lds_h(b));
+        const uint32_t qh = lds_ld4<2>(b + 2) >> (8 * j);
+        const u32x2 t = legacy_nibbles<2>(b + 6, j);
+        const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 16.0f);
+        const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 16.0f);
+        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+    }
+};
+
+// dequant.py:71-85    [d][m][qh u32][qs x16]        out = rn(rn(d * q) + m)
+struct FmtQ5_1 {
+    static constexpr int ID = 7, BS = 32, TS = 24, LDS_ALIGN = 8;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 dm = as_h2(lds_ld4<4>(b));
+        const h2 d = bcast_lo(dm), m = bcast_hi(dm);
+        const uint32_t qh = lds_ld4<4>(b + 4) >> (8 * j);
+        const u32x2 t = legacy_nibbles<8>(b + 8, j);
+        const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 0.0f);
+        const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 0.0f);
+        return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
+    }
+};
+
+// dequant.py:241 KVALUES as bytes; nibble -> int8 through two v_perm_b32 and a v_bfi_b32
+GGQ_DEV uint32_t kvalues4(uint32_t t /* 4 nibble-bytes */)
+{
+    // { -127,-104,-83,-65, -49,-35,-22,-10,  1,13,25,38, 53,69,89,113 }
+    constexpr uint32_t K0 = 0xBFAD9881u, K1 = 0xF6EADDCFu, K2 = 0x26190D01u, K3 = 0x71594535u;
+    const uint32_t sel = t & 0x07070707u;
+    const uint32_t lo = __builtin_amdgcn_perm(K1, K0, sel), hi = __builtin_amdgcn_perm(K3, K2, sel);
+    const uint32_t m = ((t >> 3) & 0x01010101u) * 0xFFu;
+    return (hi & m) | (lo & ~m);
+}
+
+// dequant.py:243-256  [d][qs x16]                   out = rn(d * KVALUES[q])
+struct FmtIQ4_NL {
+    static constexpr int ID = 20, BS = 32, TS = 18, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const h2 d = splat(lds_h(b));
+        const u32x2 t = legacy_nibbles<2>(b + 2, j);
+        const H2x2 q0 = fields_h2(kvalues4(t.x) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t.y) ^ 0x80808080u, 128.0f);
+        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+    }
+};
+
+// ---- K-quants: 256-element super-blocks, 32 chunks each; chunk j covers elements 8j..8j+7.
+
+// dequant.py:129-139 get_scale_min.  hdr = the first 16 bytes of a Q4_K / Q5_K super-block
+// ([d][dmin][scales 12], one broadcast ds_read_b128); returns (d*sc, dmin*mn) for sub-block sb.
+GGQ_DEV h2 k_dl_ml(u32x4 hdr, int sb)
+{
+    const uint32_t sh = 8u * (uint32_t)(sb & 3);
+    const uint32_t a = (hdr.y >> sh) & 0xFFu, bb = (hdr.z >> sh) & 0xFFu, c = (hdr.w >> sh) & 0xFFu;
+    const uint32_t hi = 0u - (uint32_t)(sb >> 2);                    // all-ones for sub-blocks 4..7
+    const uint32_t sc = ((a & 63u) & ~hi) | (((c & 15u) | ((a >> 2) & 0x30u)) & hi);
+    const uint32_t mn = ((bb & 63u) & ~hi) | (((c >> 4) | ((bb >> 2) & 0x30u)) & hi);
+    return as_h2(hdr.x) * ints_h2(sc | (mn << 16), 0.0f);
+}
+
+// dequant.py:180-195  [d][dmin][scales 12][qs 128]  out = rn(rn(rn(d*sc) * q) - rn(dmin*mn))
+struct FmtQ4_K {
+    static constexpr int ID = 12, BS = 256, TS = 144, LDS_ALIGN = 16;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int sb = j >> 2;
+        const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);                // (d*sc, dmin*mn)
+        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        const u32x2 w = lds_ld8<8>(b + 16 + 32 * (sb >> 1) + 8 * (j & 3));
+        const int sh = (sb & 1) * 4;
+        const H2x2 q0 = fields_h2((w.x >> sh) & 0x0F0F0F0Fu, 0.0f), q1 = fields_h2((w.y >> sh) & 0x0F0F0F0Fu, 0.0f);
+        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+    }
+};
+
+// dequant.py:159-178  [d][dmin][scales 12][qh 32][qs 128]   q = nib | bit(qh[l], sb) << 4
+struct FmtQ5_K {
+    static constexpr int ID = 13, BS = 256, TS = 176, LDS_ALIGN = 16;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int sb = j >> 2;
+        const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);
+        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        const u32x2 h = lds_ld8<8>(b + 16 + 8 * (j & 3));
+        const u32x2 w = lds_ld8<8>(b + 48 + 32 * (sb >> 1) + 8 * (j & 3));
+        const int sh = (sb & 1) * 4;
+        const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> sb) & 0x01010101u) << 4);
+        const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> sb) & 0x01010101u) << 4);
+        const H2x2 q0 = fields_h2(t0, 0.0f), q1 = fields_h2(t1, 0.0f);
+        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+    }
+};
+
+// dequant.py:141-157  [ql 128][qh 64][scales i8 x16][d]     out = rn(rn(d*scale) * (q - 32))
+struct FmtQ6_K {
+    static constexpr int ID = 14, BS = 256, TS = 210, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
+        const _Float16 sc = (_Float16)(int16_t)(int8_t)lds_u8(b + 192 + (j >> 1));
+        const h2 dl = splat(lds_h(b + 208) * sc);
+        const u32x2 w = lds_ld8<2>(b + 64 * half + 32 * (k & 1) + 8 * c4);
+        const u32x2 h = lds_ld8<2>(b + 128 + 32 * half + 8 * c4);
+        const int sh = (k >> 1) * 4;
+        const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> (2 * k)) & 0x03030303u) << 4);
+        const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> (2 * k)) & 0x03030303u) << 4);
+        const H2x2 q0 = fields_h2(t0, 32.0f), q1 = fields_h2(t1, 32.0f);
+        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+    }
+};
+
+// dequant.py:221-238  [scales 16][qs 64][d][dmin]   out = rn(rn(rn(d*(s&15)) * q) - rn(dmin*(s>>4)))
+struct FmtQ2_K {
+    static constexpr int ID = 10, BS = 256, TS = 84, LDS_ALIGN = 4;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
+        const uint32_t s = lds_u8(b + (j >> 1));
+        const h2 dlml = as_h2(lds_ld4<4>(b + 80)) * ints_h2((s & 15u) | ((s >> 4) << 16), 0.0f);
+        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        const u32x2 w = lds_ld8<4>(b + 16 + 32 * half + 8 * c4);
+        const H2x2 q0 = fields_h2((w.x >> (2 * k)) & 0x03030303u, 0.0f), q1 = fields_h2((w.y >> (2 * k)) & 0x03030303u, 0.0f);
+        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+    }
+};
+
+// dequant.py:197-219  [hmask 32][qs 64][scales 12][d]   out = rn(rn(d*(scale-32)) * (ql - (hb ? 0 : 4)))
+struct FmtQ3_K {
+    static constexpr int ID = 11, BS = 256, TS = 110, LDS_ALIGN = 2;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3, jj = j >> 1;
+        const uint32_t lo = (lds_u8(b + 96 + (jj & 7)) >> (4 * (jj >> 3))) & 15u;
+        const uint32_t hi = (lds_u8(b + 104 + (jj & 3)) >> (2 * (jj >> 2))) & 3u;
+        const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
+        const h2 dl = splat(lds_h(b + 108) * sc);
+        const u32x2 w = lds_ld8<2>(b + 32 + 32 * half + 8 * c4);
+        const u32x2 hm = lds_ld8<2>(b + 8 * c4);
+        const int hs = j >> 2;
+        // q = ql - 4*(1-hb) = (ql | hb << 2) - 4
+        const uint32_t t0 = ((w.x >> (2 * k)) & 0x03030303u) | (((hm.x >> hs) & 0x01010101u) << 2);
+        const uint32_t t1 = ((w.y >> (2 * k)) & 0x03030303u) | (((hm.y >> hs) & 0x01010101u) << 2);
+        const H2x2 q0 = fields_h2(t0, 4.0f), q1 = fields_h2(t1, 4.0f);
+        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+    }
+};
+
+// dequant.py:258-285  [d][scales_h u16][scales_l 4][qs 128]   out = rn(rn(d*(scale-32)) * KVALUES[q])
+struct FmtIQ4_XS {
+    static constexpr int ID = 23, BS = 256, TS = 136, LDS_ALIGN = 8;
+    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    {
+        const int g = j >> 2, c4 = j & 3;
+        const uint32_t lo = (lds_u8(b + 4 + (g >> 1)) >> (4 * (g & 1))) & 15u;
+        const uint32_t hi = (lds_u16(b + 2) >> (2 * g)) & 3u;
+        const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
+        const h2 dl = splat(lds_h(b) * sc);
+        const u32x2 w = lds_ld8<8>(b + 8 + 16 * g + 8 * (c4 & 1));
+        const int sh = (c4 >> 1) * 4;
+        const uint32_t t0 = (w.x >> sh) & 0x0F0F0F0Fu, t1 = (w.y >> sh) & 0x0F0F0F0Fu;
+        const H2x2 q0 = fields_h2(kvalues4(t0) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t1) ^ 0x80808080u, 128.0f);
+        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+    }
+};
+
+// ============================================================================ output stage
+// The reference's dequantize_tensor ends with `.to(dtype)` (dequant.py:23): one cast of the fp16
+// result.  OUT = 0 keeps fp16; 1 / 2 fuse that cast (fp16 -> bf16 RNE, fp16 -> fp32 exact) into
+// the store so the dense tensor is written once instead of written, re-read and re-written.
+enum : int { OUT_F16 = 0, OUT_BF16 = 1, OUT_F32 = 2 };
+
+template <int OUT> struct OutBytes { static constexpr int V = 2; };
+template <> struct OutBytes<OUT_F32> { static constexpr int V = 4; };
+
+template <bool NT, class T>
+GGQ_DEV void gstore(T* p, T v)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <bool NT>
+GGQ_DEV u32x4 gload16(const uint8_t* p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+}
+
+GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh)
+{
+    const h2 v = as_h2(hh);
+    const uint32_t a = __builtin_bit_cast(uint32_t, (float)v.x), b = __builtin_bit_cast(uint32_t, (float)v.y);
+    // fp16 -> fp32 is exact; fp32 -> bf16 round-to-nearest-even, NaN kept quiet
+    auto rne = [](uint32_t u) -> uint32_t {
+        const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+        return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? ((u >> 16) | 0x0040u) : r;
+    };
+    return rne(a) | (rne(b) << 16);
+}
+
+template <int OUT, bool NT>
+GGQ_DEV void store_chunk(uint8_t* out, uint64_t elem, u32x4 v)
+{
+    if constexpr (OUT == OUT_F16) {
+        gstore<NT>(reinterpret_cast<u32x4*>(out + elem * 2), v);
+    } else if constexpr (OUT == OUT_BF16) {
+        const u32x4 r{h2_to_bf16x2(v.x), h2_to_bf16x2(v.y), h2_to_bf16x2(v.z), h2_to_bf16x2(v.w)};
+        gstore<NT>(reinterpret_cast<u32x4*>(out + elem * 2), r);
+    } else {
+        const h2 a = as_h2(v.x), b = as_h2(v.y), c = as_h2(v.z), d = as_h2(v.w);
+        f32x4* p = reinterpret_cast<f32x4*>(out + elem * 4);
+        gstore<NT>(p, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
+        gstore<NT>(p + 1, f32x4{(float)c.x, (float)c.y, (float)d.x, (float)d.y});
+    }
+}
+
+// ============================================================================ the engine
+
+// One tensor (or one contiguous run of blocks) to dequantize.  first_group = number of groups in
+// all earlier descriptors of a table (exclusive prefix sum), filled by the host.
+struct Desc {
+    const uint8_t* packed;
+    uint8_t* out;
+    uint64_t n_blocks;
+    uint64_t first_group;
+};
+
+struct Work {
+    const uint8_t* packed;
+    uint8_t* out;
+    uint64_t n_blocks;
+    uint64_t lg;   // group index inside the tensor
+};
+
+GGQ_DEV void wave_sync()
+{
+    // LDS traffic of one wave is issued and serviced in order; all that is needed between the
+    // slice fill and the cross-lane reads is that the COMPILER keeps them in program order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Launch shape: one wavefront = one group, start to finish, then the wave retires and the
+// hardware dispatcher starts the next workgroup -- no grid-stride loop.  (Measured on MI355X: a
+// persistent loop with a register prefetch of the next group is 10-15 % SLOWER, because its
+// s_waitcnt vmcnt(0) in front of the LDS fill also waits for the previous group's stores to be
+// acknowledged -- gfx950 counts loads and stores in the one vmcnt; profiles/r01_*.)
+//   F      block format            G      blocks per group
+//   OUT    output dtype            NTL/NTS  non-temporal loads / stores
+//   WAVES  wavefronts per workgroup (they share nothing but the LDS allocation)
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+struct Engine {
+    static constexpr int TS = F::TS, BS = F::BS;
+    static constexpr int CPB = BS / 8;                 // chunks per block
+    static constexpr int GROUP_BYTES = G * TS;
+    // A group starts 16-B aligned when GROUP_BYTES % 16 == 0 (any G that is a multiple of 8);
+    // otherwise its start is only MISALIGN_STEP-aligned and the wave loads from the aligned
+    // address below it, keeping the same byte offset inside its LDS slice.
+    static constexpr bool ALIGNED = GROUP_BYTES % 16 == 0;
+    static constexpr int UNITS = (GROUP_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;   // 16-B load units per group (max)
+    static constexpr int NU = (UNITS + 63) / 64;       // per lane
+    static constexpr int CHUNKS = G * CPB;
+    static constexpr int NCH = CHUNKS / 64;            // stores per lane per group
+    static constexpr int SLICE = NU * 64 * 16;         // LDS bytes per wave
+    static constexpr int THREADS = WAVES * 64;
+    static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
+    static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
+    static_assert(CHUNKS % 64 == 0, "a group must be a whole number of 1 KiB store rows");
+
+    // FULL = the whole group lies inside the tensor (wave-uniform): no per-lane bounds checks,
+    // so the compiler batches the LDS reads of all NCH chunks.
+    template <bool FULL>
+    GGQ_DEV static void body(uint8_t* slice, const Work& w, int lane)
+    {
+        const uint64_t off = w.lg * (uint64_t)GROUP_BYTES;
+        const uint32_t a = ALIGNED ? 0u : ((uint32_t)off & 15u);            // wave-uniform
+        const uint8_t* base = w.packed + off - a;
+        uint32_t valid = a + (uint32_t)GROUP_BYTES;
+        if constexpr (!FULL) {
+            const uint64_t left = w.n_blocks * (uint64_t)TS - off;           // > 0 by construction
+            if (left < (uint64_t)GROUP_BYTES) valid = a + (uint32_t)left;
+        }
+        u32x4 pf[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const uint32_t o = (uint32_t)(lane + 64 * u) * 16u;
+            if (FULL && ALIGNED && (u + 1) * 64 <= UNITS) {
+                pf[u] = gload16<NTL>(base + o);
+            } else {
+                // the last unit of a tensor may straddle its end: an aligned 16-B read never crosses
+                // a page, so the over-read (< 16 B, inside the same aligned unit) cannot fault.
+                pf[u] = (o < valid) ? gload16<NTL>(base + o) : u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+        wave_sync();
+        const uint64_t b0 = w.lg * (uint64_t)G;
+#pragma unroll
+        for (int s = 0; s < NCH; s++) {
+            const int chunk = lane + 64 * s;
+            const int bl = chunk / CPB, j = chunk % CPB;
+            const uint64_t gb = b0 + (uint64_t)bl;
+            if (FULL || gb < w.n_blocks) {
+                const u32x4 v = F::chunk(slice + a + bl * TS, j);
+                store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
+            }
+        }
+    }
+
+    template <class Locate>
+    GGQ_DEV static void run(uint64_t total_groups, Locate locate)
+    {
+        __shared__ __attribute__((aligned(16))) uint8_t smem[WAVES * SLICE];
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int lane = (int)(threadIdx.x & 63);
+        uint32_t bid = blockIdx.x;
+        if constexpr (XCD) {
+            // workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only): give each
+            // XCD one contiguous eighth of the work instead of every eighth workgroup.
+            const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = bid & 7u;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        }
+        const uint64_t g = (uint64_t)bid * WAVES + (uint64_t)wave;
+        if (g >= total_groups) return;
+        const Work w = locate(g);
+        uint8_t* slice = smem + wave * SLICE;
+        if ((w.lg + 1) * (uint64_t)G <= w.n_blocks) body<true>(slice, w, lane);
+        else body<false>(slice, w, lane);
+    }
+};
+
+// one tensor, descriptor by value
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+__global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups)
+{
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD>::run(total_groups, [&](uint64_t g) { return Work{d.packed, d.out, d.n_blocks, g}; });
+}
+
+// many tensors of one format: table in device memory, sorted by first_group
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+__global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups)
+{
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD>::run(total_groups, [&](uint64_t g) {
+        uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (table[mid].first_group <= g) lo = mid; else hi = mid;
+        }
+        const Desc d = table[lo];
+        return Work{d.packed, d.out, d.n_blocks, g - d.first_group};
+    });
+}
+
+}  // namespace ggq

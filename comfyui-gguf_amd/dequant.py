@@ -1,0 +1,157 @@
+"""Host side of the MI355X dequant path: same names, arguments and results as the reference's
+dequant.py (city96/ComfyUI-GGUF), backed by the hand-written HIP kernels behind include/ggq.h.
+
+Mirrored surface (reference file:line):
+    TORCH_COMPATIBLE_QTYPES / is_torch_compatible / is_quantized      dequant.py:7-13
+    dequantize_tensor(tensor, dtype=None, dequant_dtype=None)          dequant.py:15-28
+    dequantize(data, qtype, oshape, dtype=None)                        dequant.py:30-44
+    dequantize_functions  {qtype: fn(blocks, block_size, type_size, dtype=None)}   dequant.py:287-301
+
+What runs where
+    * packed bytes on an AMD GPU, default arithmetic (dequant_dtype None / float16): the HIP
+      kernels -- bit-identical to the reference's eager fp16 op sequence.  The final
+      ``.to(dtype)`` of dequantize_tensor (dequant.py:23) is fused into the store for
+      dtype in {float16, bfloat16, float32}; any other dtype gets the same single torch cast.
+    * BF16 "blocks" (dequant.py:61-62) are a pure bit reinterpretation -> one torch op on device.
+    * anything else -- CPU tensors, dequant_dtype float32/bfloat16 arithmetic, unknown qtypes --
+      is NOT served here: :class:`GGQUnsupported` is raised.  There is deliberately no CPU or torch
+      re-implementation in this package; ``install()`` (install.py) wires this module in front of
+      the reference's own functions, which keep handling those cases.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+from .qtypes import GGMLQuantizationType, GGML_QUANT_SIZES, HIP_QTYPES
+
+Q = GGMLQuantizationType
+
+TORCH_COMPATIBLE_QTYPES = (None, Q.F32, Q.F16)
+
+_OUT_CODE = {torch.float16: _native.OUT_F16, torch.bfloat16: _native.OUT_BF16, torch.float32: _native.OUT_F32}
+
+
+class GGQUnsupported(NotImplementedError):
+    """The request is outside what the HIP path serves (see module docstring)."""
+
+
+def is_torch_compatible(tensor):
+    return tensor is None or getattr(tensor, "tensor_type", None) in TORCH_COMPATIBLE_QTYPES
+
+
+def is_quantized(tensor):
+    return not is_torch_compatible(tensor)
+
+
+def _qtype_key(qtype):
+    try:
+        return Q(int(qtype))
+    except (ValueError, TypeError):
+        return None
+
+
+def hip_supported(qtype):
+    return _qtype_key(qtype) in HIP_QTYPES
+
+
+def _as_bytes(data):
+    """dequant.py:37-39: rows = data.reshape((-1, data.shape[-1])).view(torch.uint8), flattened."""
+    if type(data) is not torch.Tensor:
+        data = data.as_subclass(torch.Tensor)          # strip GGMLTensor: plain byte buffer from here on
+    if data.dtype != torch.uint8:
+        data = data.reshape((-1, data.shape[-1])).view(torch.uint8)
+    data = data.reshape(-1)
+    if not data.is_contiguous():
+        data = data.contiguous()
+    if data.data_ptr() % 16:
+        data = data.clone()                            # fresh allocations are >= 256-B aligned
+    return data
+
+
+def _launch(qtype, data, n_blocks, out, out_code):
+    dev = data.device
+    if torch.cuda.current_device() != dev.index:
+        with torch.cuda.device(dev):
+            return _launch(qtype, data, n_blocks, out, out_code)
+    stream = torch.cuda.current_stream(dev).cuda_stream   # order after the H2D copy, before F.linear
+    rc = _native.lib().ggq_dequant(int(qtype), data.data_ptr(), n_blocks, out.data_ptr(), out_code, stream)
+    _native.check(rc, f"ggq_dequant({Q(int(qtype)).name})")
+
+
+def _dequant_hip(data, qtype, out_dtype):
+    """Packed device bytes -> flat dense tensor of ``out_dtype`` (fp16 math, then one cast)."""
+    key = _qtype_key(qtype)
+    if key not in HIP_QTYPES:
+        raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r}")
+    if not data.is_cuda:
+        raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
+    block_size, type_size = GGML_QUANT_SIZES[key]
+    data = _as_bytes(data)
+    n_blocks = data.numel() // type_size                  # dequant.py:41
+    out = torch.empty(n_blocks * block_size, dtype=out_dtype, device=data.device)
+    if n_blocks:
+        _launch(key, data, n_blocks, out, _OUT_CODE[out_dtype])
+    return out
+
+
+def dequantize(data, qtype, oshape, dtype=None):
+    """Dequantize tensor back to usable shape/dtype (dequant.py:30-44).
+
+    ``dtype`` is the reference's *arithmetic* dtype (its ``dequant_dtype``): None / float16 is the
+    stock fp16 path and returns float16.
+    """
+    key = _qtype_key(qtype)
+    if key == Q.BF16:
+        return dequantize_blocks_BF16(_as_bytes(data), 1, 2, dtype).reshape(oshape)
+    if dtype not in (None, torch.float16):
+        raise GGQUnsupported(f"dequant_dtype={dtype}: only the default fp16 arithmetic has HIP kernels")
+    return _dequant_hip(data, qtype, torch.float16).reshape(oshape)
+
+
+def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
+    """dequant.py:15-28, same argument meaning and result."""
+    qtype = getattr(tensor, "tensor_type", None)
+    oshape = getattr(tensor, "tensor_shape", tensor.shape)
+
+    if qtype in TORCH_COMPATIBLE_QTYPES:
+        return tensor.to(dtype)
+    key = _qtype_key(qtype)
+    if key in HIP_QTYPES:
+        dequant_dtype = dtype if dequant_dtype == "target" else dequant_dtype
+        if dequant_dtype not in (None, torch.float16):
+            raise GGQUnsupported(f"dequant_dtype={dequant_dtype}: only the default fp16 arithmetic has HIP kernels")
+        if dtype in _OUT_CODE:
+            # dequantize(...).to(dtype) with the cast fused into the kernel's store
+            return _dequant_hip(tensor.data, key, dtype).reshape(oshape)
+        return _dequant_hip(tensor.data, key, torch.float16).reshape(oshape).to(dtype)
+    if key == Q.BF16:
+        return dequantize(tensor.data, key, oshape, dtype=dequant_dtype).to(dtype)
+    raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r} "
+                         "(the reference falls back to gguf's numpy dequantize here, dequant.py:24-28)")
+
+
+# ---- dequantize_functions: the reference's per-format block functions (dequant.py:287-301) --------
+
+def dequantize_blocks_BF16(blocks, block_size, type_size, dtype=None):
+    """dequant.py:61-62: (int16 -> int32 << 16) viewed as fp32 == an exact bf16 -> fp32 widening."""
+    return blocks.reshape(-1).view(torch.uint8).view(torch.bfloat16).to(torch.float32).reshape((-1, 1))
+
+
+def _make_block_fn(key):
+    def fn(blocks, block_size, type_size, dtype=None):
+        """(n_blocks, type_size) uint8 -> (n_blocks, block_size) float16, on the GPU."""
+        if dtype not in (None, torch.float16):
+            raise GGQUnsupported(f"dtype={dtype}: only the default fp16 arithmetic has HIP kernels")
+        bs, ts = GGML_QUANT_SIZES[key]
+        if (block_size, type_size) != (bs, ts):
+            raise ValueError(f"{key.name}: expected block geometry {(bs, ts)}, got {(block_size, type_size)}")
+        return _dequant_hip(blocks, key, torch.float16).reshape((-1, bs))
+    fn.__name__ = fn.__qualname__ = f"dequantize_blocks_{key.name}"
+    return fn
+
+
+dequantize_functions = {Q.BF16: dequantize_blocks_BF16}
+dequantize_functions.update({k: _make_block_fn(k) for k in HIP_QTYPES})
+for _k in HIP_QTYPES:
+    globals()[f"dequantize_blocks_{_k.name}"] = dequantize_functions[_k]

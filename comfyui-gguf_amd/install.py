@@ -1,0 +1,63 @@
+"""Drop the HIP path in behind an unmodified ComfyUI-GGUF checkout.
+
+    import ComfyUI_GGUF.dequant as ref_dequant, ComfyUI_GGUF.ops as ref_ops
+    install(ref_dequant, ref_ops)
+
+replaces ``dequantize`` and ``dequantize_tensor`` (reference dequant.py:15,30) -- and the name
+``ops.py`` imported at load time (reference ops.py:9) -- by wrappers that send GPU-resident,
+default-arithmetic requests to the HIP kernels and hand EVERYTHING ELSE to the reference's own
+original functions: CPU tensors at load time (loader.py:124,253,...), dequant_dtype float32 /
+bfloat16 arithmetic, qtypes without a kernel.  Nothing above ``dequantize_tensor`` changes:
+``GGMLTensor``, ``GGMLOps``, the loader and the nodes keep running the reference's code, so the
+"Unet Loader (GGUF)" node works unchanged.  ``uninstall()`` restores the originals.
+"""
+import torch
+
+from . import dequant as _hip
+
+_installed = {}
+
+
+def _takes_hip(data, qtype, dequant_dtype):
+    return (isinstance(data, torch.Tensor) and data.is_cuda and _hip.hip_supported(qtype)
+            and dequant_dtype in (None, torch.float16))
+
+
+def install(ref_dequant, ref_ops=None, ref_loader=None):
+    """Patch the reference modules in place; returns the dict of original functions."""
+    if id(ref_dequant) in _installed:
+        return _installed[id(ref_dequant)]["orig"]
+    from . import _native
+    _native.lib()                                   # fail now, loudly, if the extension is absent
+    orig = {"dequantize": ref_dequant.dequantize, "dequantize_tensor": ref_dequant.dequantize_tensor}
+
+    def dequantize(data, qtype, oshape, dtype=None):
+        if _takes_hip(data, qtype, dtype):
+            return _hip.dequantize(data, qtype, oshape, dtype=dtype)
+        return orig["dequantize"](data, qtype, oshape, dtype=dtype)
+
+    def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
+        qtype = getattr(tensor, "tensor_type", None)
+        resolved = dtype if dequant_dtype == "target" else dequant_dtype
+        if qtype not in ref_dequant.TORCH_COMPATIBLE_QTYPES and _takes_hip(tensor, qtype, resolved):
+            return _hip.dequantize_tensor(tensor, dtype, dequant_dtype)
+        return orig["dequantize_tensor"](tensor, dtype, dequant_dtype)
+
+    dequantize.__wrapped__ = orig["dequantize"]
+    dequantize_tensor.__wrapped__ = orig["dequantize_tensor"]
+    ref_dequant.dequantize = dequantize
+    ref_dequant.dequantize_tensor = dequantize_tensor
+    patched = [(ref_dequant, "dequantize", orig["dequantize"]), (ref_dequant, "dequantize_tensor", orig["dequantize_tensor"])]
+    for mod in (ref_ops, ref_loader):               # `from .dequant import dequantize_tensor` bound the old object
+        if mod is not None and getattr(mod, "dequantize_tensor", None) is orig["dequantize_tensor"]:
+            mod.dequantize_tensor = dequantize_tensor
+            patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
+    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched}
+    return orig
+
+
+def uninstall(ref_dequant):
+    rec = _installed.pop(id(ref_dequant), None)
+    if rec:
+        for mod, name, fn in rec["patched"]:
+            setattr(mod, name, fn)

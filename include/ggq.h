@@ -1,0 +1,108 @@
+/*
+ * ggq.h -- C ABI of libggq_hip.so: MI355X (gfx950) GGUF block dequantization.
+ *
+ * This is the drop-in boundary for the one hot path of city96/ComfyUI-GGUF, dequant.py.
+ * The reference has no FFI of its own (it is eager torch code); each entry point below names the
+ * reference interface it stands in for, and INTEGRATION.md shows the ctypes binding a maintainer
+ * adds on the reference side.  Plain pointers and sizes only -- no torch types cross this line.
+ *
+ * Conventions
+ *   - every function returns a ggq_status (0 = GGQ_OK) and never throws, aborts or syncs the device;
+ *   - `packed` / `out` are DEVICE pointers on the current HIP device; `packed` is borrowed and
+ *     read-only, `out` is caller-allocated (torch's caching allocator owns it) and only filled;
+ *   - `hip_stream` is a hipStream_t passed as void* (NULL = the legacy default stream); kernels are
+ *     enqueued on it and the call returns immediately -- pass torch's CURRENT stream so the launch
+ *     orders after the H2D copy before it and before the F.linear after it (ops.py:209-210,244);
+ *   - re-entrant and thread-safe: no global mutable state except a per-device property cache;
+ *   - `packed` and `out` must be 16-byte aligned (GGQ_ERR_ALIGN otherwise; torch allocations are);
+ *   - `qtype` is ggml's public type id (== int(gguf.GGMLQuantizationType.X)):
+ *       Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14 IQ4_NL=20 IQ4_XS=23.
+ *
+ * Numerics: bit-identical to the reference's default fp16 path (dequant_dtype=None,
+ * nodes.py:152-153): every torch op of a block function is one correctly rounded fp16 op here too.
+ */
+#ifndef GGQ_H
+#define GGQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ggq_status {
+    GGQ_OK = 0,
+    GGQ_ERR_QTYPE = 1,   /* qtype has no HIP unpacker (caller keeps the reference path, dequant.py:24-28) */
+    GGQ_ERR_ALIGN = 2,   /* packed or out not 16-byte aligned */
+    GGQ_ERR_ARG = 3,     /* NULL pointer with n_blocks > 0, bad out_dtype, bad descriptor table */
+    GGQ_ERR_HIP = 4,     /* a HIP runtime call failed; ggq_last_hip_error() has the hipError_t */
+    GGQ_ERR_NOMEM = 5    /* host or device allocation for a plan failed */
+} ggq_status;
+
+/* dtype of the dense output.  F16 is the reference's dequantize() result (dequant.py:30-44);
+ * BF16 / F32 additionally fuse the single `.to(dtype)` cast that dequantize_tensor applies to
+ * that fp16 result (dequant.py:23) -- same values as dequantize(...).to(dtype), one pass. */
+typedef enum ggq_out_dtype { GGQ_OUT_F16 = 0, GGQ_OUT_BF16 = 1, GGQ_OUT_F32 = 2 } ggq_out_dtype;
+
+/* ---- queries ------------------------------------------------------------------------------- */
+
+/* 1 if `qtype` has a HIP unpacker.  Replaces: `qtype in dequantize_functions` (dequant.py:21,287-301). */
+int ggq_supported(int qtype);
+
+/* Elements / bytes per block, 0 for an unknown qtype.  Replaces: gguf.GGML_QUANT_SIZES[qtype] (dequant.py:34). */
+int ggq_block_size(int qtype);
+int ggq_type_size(int qtype);
+
+/* Static message for a ggq_status. */
+const char* ggq_strerror(int status);
+
+/* hipError_t (as int) of the most recent failing HIP call on this thread, 0 if none. */
+int ggq_last_hip_error(void);
+
+/* Library ABI version (bumped on any signature change). */
+int ggq_abi_version(void);
+
+/* ---- one tensor ---------------------------------------------------------------------------- */
+
+/* Dequantize n_blocks consecutive blocks: packed[n_blocks * type_size] -> out[n_blocks * block_size].
+ * Replaces: dequantize(data, qtype, oshape, dtype=None) (dequant.py:30-44) -- the framing
+ * (n_blocks = numel // type_size, output element b*block_size+j = block b element j) is the
+ * caller's reshape; and dequantize_functions[qtype](blocks, block_size, type_size) (dequant.py:43).
+ * n_blocks == 0 is a no-op that returns GGQ_OK. */
+int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int out_dtype, void* hip_stream);
+
+/* Same with out_dtype = GGQ_OUT_F16 (the reference's own result dtype). */
+int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream);
+
+/* ---- many tensors, one call (the weight set of a model) ------------------------------------- */
+
+/* One entry per tensor.  Replaces: one dequantize_tensor() call per layer (ops.py:177). */
+typedef struct ggq_desc {
+    int32_t qtype;
+    int32_t out_dtype;      /* ggq_out_dtype */
+    const void* packed;     /* device, 16-B aligned */
+    void* out;              /* device, 16-B aligned */
+    uint64_t n_blocks;
+} ggq_desc;
+
+typedef struct ggq_plan ggq_plan;
+
+/* Build a launch plan for `n` tensors on the current device: descriptors are grouped by
+ * (qtype, out_dtype), their work is prefix-summed and the tables are copied to device memory
+ * once (synchronous, load-time).  Pointers are captured, not the bytes: the plan stays valid
+ * while the tensors keep their addresses (packed weights resident in HBM). */
+int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out);
+
+/* Enqueue the whole plan on `hip_stream`: one kernel per (qtype, out_dtype) present. */
+int ggq_plan_launch(const ggq_plan* plan, void* hip_stream);
+
+/* Algorithmic bytes one launch moves (packed read + dense write), and its kernel count. */
+uint64_t ggq_plan_bytes(const ggq_plan* plan);
+uint32_t ggq_plan_kernels(const ggq_plan* plan);
+
+void ggq_plan_destroy(ggq_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGQ_H */

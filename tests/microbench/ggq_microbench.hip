@@ -1,0 +1,379 @@
+// ggq_microbench.hip -- standalone MI355X harness (test infrastructure, lives under tests/):
+//   1. parity of every HIP unpacker (through the C ABI of libggq_hip.so) against the CPU oracle
+//      (oracle/ggq_oracle.c, linked in) on seeded blocks incl. adversarial scale fields and ragged sizes;
+//   2. HBM ceilings for this traffic mix (fill / copy / "0.5625 B read + 2 B write" streams);
+//   3. timing of kernel variants (group size G, non-temporal access, grid cap) instantiated
+//      straight from ggq_device.hpp, over a working set >> the 256 MiB Infinity Cache.
+// Build: see tests/microbench/Makefile.   Run: ./ggq_microbench [parity|ceil|variants|formats|all]
+#include "../../comfyui-gguf_amd/csrc/ggq_device.hpp"
+#include "../../include/ggq.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+int ggq_oracle_dequant_f16(int qtype, const uint8_t* packed, uint64_t n_blocks, uint16_t* out);
+void ggq_oracle_cast_f16_to_bf16(const uint16_t* in, uint64_t n, uint16_t* out);
+void ggq_oracle_cast_f16_to_f32(const uint16_t* in, uint64_t n, float* out);
+int ggq_oracle_block_size(int qtype);
+int ggq_oracle_type_size(int qtype);
+}
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rng() { uint64_t x = rng_state; x ^= x << 13; x ^= x >> 7; x ^= x << 17; return rng_state = x; }
+
+struct QT { int id; const char* name; int scale_off[2]; };
+static const QT QTS[] = {
+    {2, "Q4_0", {0, -1}}, {3, "Q4_1", {0, 2}}, {6, "Q5_0", {0, -1}}, {7, "Q5_1", {0, 2}}, {8, "Q8_0", {0, -1}},
+    {10, "Q2_K", {80, 82}}, {11, "Q3_K", {108, -1}}, {12, "Q4_K", {0, 2}}, {13, "Q5_K", {0, 2}}, {14, "Q6_K", {208, -1}},
+    {20, "IQ4_NL", {0, -1}}, {23, "IQ4_XS", {0, -1}},
+};
+
+static uint16_t f2h_pos(float f)  // positive normal floats only (nominal scales)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    int e = (int)((u >> 23) & 255) - 127 + 15;
+    uint32_t m = (u >> 13) & 1023;
+    if (e <= 0) return 0x0001;
+    return (uint16_t)((e << 10) | m);
+}
+
+static const uint16_t HARD[] = {0x0000, 0x8000, 0x0001, 0x8001, 0x03FF, 0x83FF, 0x0400, 0x8400, 0x7BFF, 0xFBFF, 0x7C00, 0xFC00,
+                                0x7E00, 0x3C00, 0xBC00, 0x3C01, 0x3555, 0x2E66, 0x1400, 0x1001, 0x5640, 0x6400, 0x7000, 0xB555, 0x9400, 0xD640};
+
+static void make_blocks(const QT& q, uint64_t n, int mode, std::vector<uint8_t>& out)
+{
+    const int ts = ggq_oracle_type_size(q.id);
+    out.resize(n * ts + 64);
+    uint64_t* p = reinterpret_cast<uint64_t*>(out.data());
+    for (size_t i = 0; i < out.size() / 8; i++) p[i] = rng();
+    const bool legacy = ggq_oracle_block_size(q.id) == 32 && q.id != 20;
+    for (uint64_t b = 0; b < n; b++) {
+        for (int k = 0; k < 2; k++) {
+            if (q.scale_off[k] < 0) continue;
+            uint16_t h;
+            const uint64_t r = rng();
+            if (mode == 0) {   // nominal (signed on odd blocks)
+                const float lo = legacy ? 1e-3f : 1e-4f, hi = legacy ? 2.1e-2f : 2e-3f;
+                h = f2h_pos(lo + (hi - lo) * (float)((r >> 11) * (1.0 / 9007199254740992.0)));
+                if ((b & 1) && (r & 1)) h |= 0x8000;
+            } else {           // adversarial
+                const unsigned pick = (unsigned)(r % (sizeof(HARD) / 2 + 6));
+                h = pick < sizeof(HARD) / 2 ? HARD[pick] : (uint16_t)(r >> 20);
+            }
+            out[b * ts + q.scale_off[k]] = (uint8_t)(h & 255);
+            out[b * ts + q.scale_off[k] + 1] = (uint8_t)(h >> 8);
+        }
+    }
+}
+
+static inline uint16_t canon16(uint16_t h) { return (h & 0x7FFF) > 0x7C00 ? 0x7E00 : h; }
+static inline uint16_t canonbf(uint16_t h) { return (h & 0x7FFF) > 0x7F80 ? 0x7FC0 : h; }
+
+static int parity()
+{
+    int failures = 0;
+    const uint64_t sizes_legacy[] = {1, 63, 64, 65, 4097, 300007};
+    const uint64_t sizes_k[] = {1, 7, 8, 9, 513, 40003};
+    for (const QT& q : QTS) {
+        const int bs = ggq_oracle_block_size(q.id), ts = ggq_oracle_type_size(q.id);
+        if (!ggq_supported(q.id) || ggq_block_size(q.id) != bs || ggq_type_size(q.id) != ts) { printf("PARITY %s: geometry/support mismatch\n", q.name); failures++; continue; }
+        for (int mode = 0; mode < 2; mode++) {
+            for (int si = 0; si < 6; si++) {
+                const uint64_t n = bs == 32 ? sizes_legacy[si] : sizes_k[si];
+                std::vector<uint8_t> packed;
+                make_blocks(q, n, mode, packed);
+                std::vector<uint16_t> want(n * bs), got(n * bs), wantbf(n * bs), gotbf(n * bs);
+                std::vector<float> want32(n * bs), got32(n * bs);
+                ggq_oracle_dequant_f16(q.id, packed.data(), n, want.data());
+                ggq_oracle_cast_f16_to_bf16(want.data(), n * bs, wantbf.data());
+                ggq_oracle_cast_f16_to_f32(want.data(), n * bs, want32.data());
+                uint8_t* dp; uint8_t* dout;
+                HIP_CHECK(hipMalloc(&dp, packed.size()));
+                HIP_CHECK(hipMalloc(&dout, n * bs * 4 + 256));
+                HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
+                uint64_t bad[3] = {0, 0, 0};
+                for (int od = 0; od < 3; od++) {
+                    HIP_CHECK(hipMemset(dout, 0xCD, n * bs * 4 + 256));
+                    const int rc = ggq_dequant(q.id, dp, n, dout, od, nullptr);
+                    if (rc) { printf("PARITY %s: ggq_dequant rc=%d (%s)\n", q.name, rc, ggq_strerror(rc)); failures++; continue; }
+                    HIP_CHECK(hipDeviceSynchronize());
+                    uint8_t guard[256];
+                    const size_t ob = (size_t)n * bs * (od == 2 ? 4 : 2);
+                    HIP_CHECK(hipMemcpy(guard, dout + ob, 256, hipMemcpyDeviceToHost));
+                    for (int g = 0; g < 256; g++) if (guard[g] != 0xCD) { bad[od]++; break; }   // wrote past the end
+                    if (od == 0) {
+                        HIP_CHECK(hipMemcpy(got.data(), dout, ob, hipMemcpyDeviceToHost));
+                        for (uint64_t i = 0; i < n * bs; i++) bad[0] += canon16(got[i]) != canon16(want[i]);
+                    } else if (od == 1) {
+                        HIP_CHECK(hipMemcpy(gotbf.data(), dout, ob, hipMemcpyDeviceToHost));
+                        for (uint64_t i = 0; i < n * bs; i++) bad[1] += canonbf(gotbf[i]) != canonbf(wantbf[i]);
+                    } else {
+                        HIP_CHECK(hipMemcpy(got32.data(), dout, ob, hipMemcpyDeviceToHost));
+                        for (uint64_t i = 0; i < n * bs; i++) {
+                            uint32_t a, b; memcpy(&a, &got32[i], 4); memcpy(&b, &want32[i], 4);
+                            const bool an = (a & 0x7FFFFFFF) > 0x7F800000, bn = (b & 0x7FFFFFFF) > 0x7F800000;
+                            bad[2] += (an || bn) ? (an != bn) : (a != b);
+                        }
+                    }
+                }
+                if (bad[0] | bad[1] | bad[2]) {
+                    failures++;
+                    printf("PARITY %-6s mode=%d n_blocks=%-7llu MISMATCH f16=%llu bf16=%llu f32=%llu\n", q.name, mode, (unsigned long long)n,
+                           (unsigned long long)bad[0], (unsigned long long)bad[1], (unsigned long long)bad[2]);
+                    if (bad[0]) for (uint64_t i = 0, shown = 0; i < n * bs && shown < 6; i++) if (canon16(got[i]) != canon16(want[i])) { printf("    elem %llu (blk %llu el %llu): got %04x want %04x\n", (unsigned long long)i, (unsigned long long)(i / bs), (unsigned long long)(i % bs), got[i], want[i]); shown++; }
+                }
+                HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(dout));
+            }
+        }
+        printf("PARITY %-6s %s\n", q.name, failures ? "(see above)" : "bit-exact (f16, bf16, f32 outputs; 6 sizes x 2 modes)");
+        fflush(stdout);
+    }
+    printf("PARITY total failures: %d\n", failures);
+    return failures;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); }
+    template <class Fn> void run(Fn fn, int warm, int reps, double& med_ms, double& min_ms)
+    {
+        for (int i = 0; i < warm; i++) fn();
+        std::vector<float> t(reps);
+        for (int i = 0; i < reps; i++) {
+            HIP_CHECK(hipEventRecord(a, nullptr));
+            fn();
+            HIP_CHECK(hipEventRecord(b, nullptr));
+            HIP_CHECK(hipEventSynchronize(b));
+            HIP_CHECK(hipEventElapsedTime(&t[i], a, b));
+        }
+        std::sort(t.begin(), t.end());
+        med_ms = t[reps / 2]; min_ms = t[0];
+    }
+};
+
+__global__ void k_fill_rand(uint64_t* p, uint64_t n, uint64_t seed)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull ^ seed; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        p[i] = x;
+    }
+}
+__global__ void k_fix_scales(uint8_t* p, uint64_t n_blocks, int ts, int off0, int off1, int legacy)
+{
+    for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x) {
+        // fp16 in [2^-10, 2^-9) legacy / [2^-13, 2^-12) K : exponent fixed, mantissa from the random bytes
+        const uint16_t e = legacy ? 0x1400 : 0x0800;
+        for (int k = 0; k < 2; k++) { const int off = k ? off1 : off0; if (off < 0) continue; uint8_t* s = p + b * ts + off; const uint16_t h = e | ((s[0] | (s[1] << 8)) & 0x03FF); s[0] = h & 255; s[1] = h >> 8; }
+    }
+}
+
+// streams with no arithmetic: the ceilings this traffic mix can reach
+__global__ __launch_bounds__(256) void k_fill16(ggq::u32x4* out, uint64_t n16)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) out[i] = ggq::u32x4{(uint32_t)i, 1, 2, 3};
+}
+__global__ __launch_bounds__(256) void k_copy16(const ggq::u32x4* in, ggq::u32x4* out, uint64_t n16)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_fill16nt(ggq::u32x4* out, uint64_t n16)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) __builtin_nontemporal_store(ggq::u32x4{(uint32_t)i, 1, 2, 3}, out + i);
+}
+__global__ __launch_bounds__(256) void k_copy16nt(const ggq::u32x4* in, ggq::u32x4* out, uint64_t n16)
+{
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+// per 9 units read, 32 units written (0.5625 B in : 2 B out, the Q4_0 / Q4_K mix)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_mix(const ggq::u32x4* in, ggq::u32x4* out, uint64_t n_tiles)
+{
+    // tile = 256 threads: 72 units in (threads 0..71 load), 256 units out
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        ggq::u32x4 v{1, 2, 3, 4};
+        if (threadIdx.x < 72) v = NT ? __builtin_nontemporal_load(in + t * 72 + threadIdx.x) : in[t * 72 + threadIdx.x];
+        v.x += __shfl(v.y, threadIdx.x & 7);
+        if (NT) __builtin_nontemporal_store(v, out + t * 256 + threadIdx.x); else out[t * 256 + threadIdx.x] = v;
+    }
+}
+
+static void ceilings()
+{
+    Timer T; double med, mn;
+    const uint64_t bytes = 2ull << 30;   // 2 GiB buffers
+    ggq::u32x4 *a, *b;
+    HIP_CHECK(hipMalloc(&a, bytes)); HIP_CHECK(hipMalloc(&b, bytes));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(a), bytes / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    const uint64_t n16 = bytes / 16;
+    for (int grid : {2048, 65536, 524288}) {
+        T.run([&] { k_fill16nt<<<grid, 256>>>(b, n16); }, 3, 15, med, mn);
+        printf("CEIL fill16nt grid=%-6d  %8.1f GB/s (median)  %8.1f GB/s (best)\n", grid, bytes / med / 1e6, bytes / mn / 1e6);
+        T.run([&] { k_copy16nt<<<grid, 256>>>(a, b, n16); }, 3, 15, med, mn);
+        printf("CEIL copy16nt grid=%-6d  %8.1f GB/s (median)  %8.1f GB/s (best)   [read+write]\n", grid, 2.0 * bytes / med / 1e6, 2.0 * bytes / mn / 1e6);
+        T.run([&] { k_fill16<<<grid, 256>>>(b, n16); }, 3, 15, med, mn);
+        printf("CEIL fill16   grid=%-6d  %8.1f GB/s (median)  %8.1f GB/s (best)\n", grid, bytes / med / 1e6, bytes / mn / 1e6);
+        T.run([&] { k_copy16<<<grid, 256>>>(a, b, n16); }, 3, 15, med, mn);
+        printf("CEIL copy16   grid=%-6d  %8.1f GB/s (median)  %8.1f GB/s (best)   [read+write]\n", grid, 2.0 * bytes / med / 1e6, 2.0 * bytes / mn / 1e6);
+        const uint64_t tiles = bytes / 4096;   // writes all of b, reads 72/256 of a
+        const double mixbytes = (double)tiles * (72 + 256) * 16;
+        T.run([&] { k_mix<false><<<grid, 256>>>(a, b, tiles); }, 3, 15, med, mn);
+        printf("CEIL mix9:32  grid=%-6d  %8.1f GB/s (median)  %8.1f GB/s (best)\n", grid, mixbytes / med / 1e6, mixbytes / mn / 1e6);
+        T.run([&] { k_mix<true><<<grid, 256>>>(a, b, tiles); }, 3, 15, med, mn);
+        printf("CEIL mix9:32nt grid=%-6d %8.1f GB/s (median)  %8.1f GB/s (best)\n", grid, mixbytes / med / 1e6, mixbytes / mn / 1e6);
+        fflush(stdout);
+    }
+    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
+}
+
+// A pool of FLUX.1-dev-shaped linears (3072x3072 and 3072x12288), `pairs` of each, one format.
+struct Pool {
+    std::vector<ggq::Desc> descs;     // host copy (first_group filled per G at launch time)
+    std::vector<uint64_t> nblk;
+    uint8_t* packed = nullptr; uint8_t* out = nullptr;
+    uint64_t packed_bytes = 0, out_bytes = 0, elements = 0;
+    int bs = 0, ts = 0;
+};
+
+static Pool make_pool(const QT& q, int pairs)
+{
+    Pool P; P.bs = ggq_oracle_block_size(q.id); P.ts = ggq_oracle_type_size(q.id);
+    const uint64_t shapes[2] = {3072ull * 3072, 3072ull * 12288};
+    for (int i = 0; i < pairs; i++) for (uint64_t el : shapes) { P.nblk.push_back(el / P.bs); P.elements += el; }
+    for (uint64_t nb : P.nblk) { P.packed_bytes += (nb * P.ts + 255) / 256 * 256; }
+    P.out_bytes = P.elements * 2;
+    HIP_CHECK(hipMalloc(&P.packed, P.packed_bytes)); HIP_CHECK(hipMalloc(&P.out, P.out_bytes));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(P.packed), P.packed_bytes / 8, q.id);
+    uint64_t po = 0, oo = 0;
+    const bool legacy = P.bs == 32 && q.id != 20;
+    for (uint64_t nb : P.nblk) {
+        k_fix_scales<<<2048, 256>>>(P.packed + po, nb, P.ts, q.scale_off[0], q.scale_off[1], legacy ? 1 : 0);
+        P.descs.push_back(ggq::Desc{P.packed + po, P.out + oo, nb, 0});
+        po += (nb * P.ts + 255) / 256 * 256; oo += nb * P.bs * 2;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    return P;
+}
+static void free_pool(Pool& P) { HIP_CHECK(hipFree(P.packed)); HIP_CHECK(hipFree(P.out)); }
+
+// parity of an arbitrary instantiation (variants other than the shipped one) vs the oracle
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD>
+static bool check_variant()
+{
+    const QT* q = nullptr;
+    for (const QT& x : QTS) if (x.id == F::ID) q = &x;
+    bool ok = true;
+    for (uint64_t n : {(uint64_t)1, (uint64_t)(G - 1 > 0 ? G - 1 : 1), (uint64_t)G, (uint64_t)(3 * G + 1), (uint64_t)(F::BS == 32 ? 20011 : 2503)}) {
+        std::vector<uint8_t> packed; make_blocks(*q, n, (int)(n & 1), packed);
+        std::vector<uint16_t> want(n * F::BS), got(n * F::BS);
+        ggq_oracle_dequant_f16(F::ID, packed.data(), n, want.data());
+        uint8_t *dp, *dout;
+        HIP_CHECK(hipMalloc(&dp, packed.size())); HIP_CHECK(hipMalloc(&dout, n * F::BS * 2 + 256));
+        HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
+        const uint64_t groups = (n + G - 1) / G;
+        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD>), dim3((uint32_t)((groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+                           ggq::Desc{dp, dout, n, 0}, groups);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
+        uint8_t guard[256]; HIP_CHECK(hipMemcpy(guard, dout + n * F::BS * 2, 256, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n * F::BS; i++) ok &= canon16(got[i]) == canon16(want[i]);
+        for (int g = 0; g < 256; g++) ok &= guard[g] == 0xCD;
+        HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(dout));
+    }
+    return ok;
+}
+
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD>
+static void time_variant(const char* name, Pool& P, Timer& T)
+{
+    const bool ok = check_variant<F, G, NTL, NTS, WAVES, XCD>();
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    const uint64_t blocks = (groups + WAVES - 1) / WAVES;
+    double med, mn;
+    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups); }, 3, 31, med, mn);
+    const double bytes = (double)P.elements * (2.0 + (double)P.ts / P.bs);
+    printf("VAR %-6s G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
+           (unsigned long long)blocks, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6, ok ? "ok" : "MISMATCH");
+    fflush(stdout);
+    HIP_CHECK(hipFree(dt));
+}
+
+template <class F, int G>
+static void sweep_w(const char* name, Pool& P, Timer& T)
+{
+    time_variant<F, G, true, true, 1, false>(name, P, T);
+    time_variant<F, G, true, true, 2, false>(name, P, T);
+    time_variant<F, G, true, true, 4, false>(name, P, T);
+    time_variant<F, G, true, true, 8, false>(name, P, T);
+}
+
+template <class F, int GA, int GB, int GC>
+static void sweep(const char* name, int qi)
+{
+    Timer T;
+    Pool P = make_pool(QTS[qi], 12);
+    sweep_w<F, GA>(name, P, T); sweep_w<F, GB>(name, P, T); sweep_w<F, GC>(name, P, T);
+    time_variant<F, GC, true, true, 4, false>(name, P, T);     // again (drift check)
+    free_pool(P);
+}
+
+static void variants()
+{
+    sweep<ggq::FmtQ4_K, 2, 4, 8>("Q4_K", 7);
+    sweep<ggq::FmtQ6_K, 2, 4, 8>("Q6_K", 9);
+    sweep<ggq::FmtQ2_K, 2, 4, 8>("Q2_K", 5);
+    sweep<ggq::FmtQ3_K, 2, 4, 8>("Q3_K", 6);
+    sweep<ggq::FmtQ4_0, 16, 32, 64>("Q4_0", 0);
+    sweep<ggq::FmtQ5_0, 16, 32, 64>("Q5_0", 2);
+    sweep<ggq::FmtQ8_0, 16, 32, 64>("Q8_0", 4);
+}
+
+// every format through the shipped library (plan API), as bench.py drives it
+static void formats()
+{
+    Timer T;
+    for (const QT& q : QTS) {
+        Pool P = make_pool(q, 12);
+        std::vector<ggq_desc> descs;
+        for (auto& d : P.descs) descs.push_back(ggq_desc{q.id, GGQ_OUT_F16, d.packed, d.out, d.n_blocks});
+        ggq_plan* plan = nullptr;
+        int rc = ggq_plan_create(descs.data(), (uint32_t)descs.size(), &plan);
+        if (rc) { printf("FMT %s: plan_create rc=%d\n", q.name, rc); continue; }
+        double med, mn;
+        T.run([&] { ggq_plan_launch(plan, nullptr); }, 3, 21, med, mn);
+        const double bytes = (double)ggq_plan_bytes(plan);
+        printf("FMT %-6s %6.2f GB/launch  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s\n", q.name, bytes / 1e9, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6);
+        fflush(stdout);
+        // single-tensor entry point on the largest tensor, back-to-back over the pool
+        T.run([&] { for (auto& d : P.descs) ggq_dequant_f16(q.id, d.packed, d.n_blocks, d.out, nullptr); }, 2, 11, med, mn);
+        printf("FMT %-6s per-tensor launches (%zu launches)  %7.3f ms  %8.1f GB/s median\n", q.name, P.descs.size(), med, bytes / med / 1e6);
+        ggq_plan_destroy(plan);
+        free_pool(P);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const std::string what = argc > 1 ? argv[1] : "all";
+    hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  clock=%d MHz  mem=%.0f GB\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.totalGlobalMem / 1e9);
+    int rc = 0;
+    if (what == "parity" || what == "all") rc |= parity();
+    if (what == "ceil" || what == "all") ceilings();
+    if (what == "formats" || what == "all") formats();
+    if (what == "variants" || what == "all") variants();
+    return rc ? 1 : 0;
+}

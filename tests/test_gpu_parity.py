@@ -1,0 +1,253 @@
+"""Parity tests proper (need an MI355X): the HIP path, called through the C ABI by the mirrored
+Python interface, against (a) the committed golden vectors produced by the reference's own
+dequant.py, (b) the CPU oracle on seeded inputs at ragged / adversarial / full BASELINE sizes,
+(c) size-independent properties.  Tolerance: NONE -- every comparison is bit-exact (NaN payloads
+canonicalised); the 1-ULP allowance of the north star is unused slack."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ALL = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"]
+DEV = "cuda:0"
+
+
+def _bits16(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16).reshape(-1)
+
+
+def _canon_bf16(bits):
+    bits = np.asarray(bits, dtype=np.uint16).copy()
+    bits[(bits & 0x7FFF) > 0x7F80] = 0x7FC0
+    return bits
+
+
+def _carrier(pkg, blocks, q, shape=None):
+    bs, _ = pkg.qtypes.block_geometry(q)
+    shape = shape or (blocks.shape[0], bs)
+    return pkg.ops.GGMLTensor(torch.from_numpy(np.ascontiguousarray(blocks).reshape(-1)).to(DEV), tensor_type=q, tensor_shape=shape)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_native(pkg):
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    pkg._native.lib()          # raises if the HIP extension is missing: no silent fallback
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_golden_vectors(pkg, golden_dir, name):
+    """HIP output == the reference's own dequant.py output, for every committed vector."""
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    q = pkg.qtypes.Q[name]
+    blocks = g["blocks"]
+    n, bs = blocks.shape[0], pkg.qtypes.block_geometry(q)[0]
+    data = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    out = pkg.dequant.dequantize(data, q, (n, bs))                          # dequant.py:30
+    assert out.dtype == torch.float16 and tuple(out.shape) == (n, bs) and out.is_cuda
+    assert np.array_equal(oracle.canon_nan_f16(_bits16(out)), oracle.canon_nan_f16(g["out_f16"].reshape(-1)))
+    half = n * bs // 2                                                       # nominal + signed runs: no NaN, raw bits
+    assert np.array_equal(_bits16(out)[:half], g["out_f16"].reshape(-1)[:half])
+    # the per-format block function of dequantize_functions (dequant.py:43)
+    fn = pkg.dequant.dequantize_functions[q]
+    out2 = fn(data.reshape(n, -1), *pkg.qtypes.block_geometry(q))
+    assert tuple(out2.shape) == (n, bs) and torch.equal(out2.view(torch.int16), out.view(torch.int16))
+    # dequantize_tensor(..., dtype=bf16): fp16 dequant + ONE cast, here fused into the store (dequant.py:23)
+    sub = blocks[g["sub"]]
+    tb = pkg.dequant.dequantize_tensor(_carrier(pkg, sub, q), torch.bfloat16)
+    assert tb.dtype == torch.bfloat16
+    assert np.array_equal(_canon_bf16(_bits16(tb)), _canon_bf16(g["tensor_bf16"].reshape(-1)))
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("mode", ["nominal", "adversarial"])
+def test_against_oracle_ragged_sizes(pkg, name, mode):
+    """Every group-boundary case: 1 block, G-1, G, G+1, several groups + a ragged tail."""
+    q = pkg.qtypes.Q[name]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    G = 64 if bs == 32 else 8
+    for n in (1, G - 1, G, G + 1, 5 * G + 3, 1031 if bs == 256 else 9001):
+        blocks = pkg.synth.make_blocks(q, n, seed=n, mode=mode)
+        want = oracle.dequant_f16(q, blocks)
+        t = _carrier(pkg, blocks, q)
+        got = pkg.dequant.dequantize_tensor(t, torch.float16)
+        assert np.array_equal(oracle.canon_nan_f16(_bits16(got)), oracle.canon_nan_f16(want)), (name, n)
+        got32 = pkg.dequant.dequantize_tensor(t, torch.float32)
+        assert got32.dtype == torch.float32
+        w32 = want.astype(np.float32)
+        g32 = got32.cpu().numpy().reshape(-1)
+        both_nan = np.isnan(w32) & np.isnan(g32)
+        assert np.array_equal(g32.view(np.uint32)[~both_nan], w32.view(np.uint32)[~both_nan]), (name, n)
+
+
+def test_trailing_bytes_and_empty(pkg):
+    """n_blocks = numel // type_size (dequant.py:41); an empty tensor is legal."""
+    q = pkg.qtypes.Q.Q5_K
+    blocks = pkg.synth.make_blocks(q, 5, seed=1)
+    ragged = np.concatenate([blocks.reshape(-1), np.arange(33, dtype=np.uint8)])
+    out = pkg.dequant.dequantize(torch.from_numpy(ragged).to(DEV), q, (5, 256))
+    assert np.array_equal(_bits16(out), oracle.dequant_f16(q, blocks).view(np.uint16))
+    empty = pkg.dequant.dequantize(torch.zeros(0, dtype=torch.uint8, device=DEV), q, (0, 256))
+    assert tuple(empty.shape) == (0, 256) and empty.dtype == torch.float16
+
+
+def test_unaligned_views_and_2d_byte_rows(pkg):
+    """The loader hands (rows, bytes_per_row) uint8 tensors (loader.py:104-106); views into a larger
+    buffer may start at any byte.  Results must not depend on either."""
+    q = pkg.qtypes.Q.Q6_K
+    blocks = pkg.synth.make_blocks(q, 24, seed=5)
+    want = oracle.dequant_f16(q, blocks).view(np.uint16)
+    rows = torch.from_numpy(blocks.reshape(2, -1).copy()).to(DEV)             # 2 rows x (12 * 210) bytes
+    assert np.array_equal(_bits16(pkg.dequant.dequantize(rows, q, (2, 12 * 256))), want)
+    for shift in (1, 2, 7, 16, 33):
+        big = torch.zeros(blocks.size + 64, dtype=torch.uint8, device=DEV)
+        big[shift:shift + blocks.size] = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+        view = big[shift:shift + blocks.size]
+        assert np.array_equal(_bits16(pkg.dequant.dequantize(view, q, (24 * 256,))), want), shift
+    # int8-typed storage of the same bytes (the reference does .view(torch.uint8), dequant.py:39)
+    as_i8 = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV).view(torch.int8)
+    assert np.array_equal(_bits16(pkg.dequant.dequantize(as_i8, q, (24 * 256,))), want)
+
+
+def test_config1_q8_0_4096x4096(pkg, golden_dir):
+    """BASELINE.json configs[0]: Q8_0 4096x4096, bit-exact vs the reference (sha256 of its output)."""
+    with open(os.path.join(golden_dir, "large_hashes.json")) as f:
+        h = json.load(f)["Q8_0:4096x4096:seed0:nominal"]
+    q = pkg.qtypes.Q.Q8_0
+    packed = pkg.synth.make_tensor_bytes(q, (4096, 4096), seed=0)
+    assert hashlib.sha256(packed.tobytes()).hexdigest() == h["packed_sha256"]
+    out = pkg.dequant.dequantize(torch.from_numpy(packed).to(DEV), q, (4096, 4096))
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == h["out_f16_sha256"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_flux_shape_B_hash(pkg, golden_dir, name):
+    """configs[1]/[2] shape B (3072x3072), every format: sha256 of the reference's output."""
+    with open(os.path.join(golden_dir, "large_hashes.json")) as f:
+        hashes = json.load(f)
+    q = pkg.qtypes.Q[name]
+    seed = 1 if q in pkg.qtypes.LEGACY_QTYPES else 2
+    h = hashes[f"{name}:3072x3072:seed{seed}:nominal"]
+    packed = pkg.synth.make_tensor_bytes(q, (3072, 3072), seed=seed)
+    out = pkg.dequant.dequantize(torch.from_numpy(packed).to(DEV), q, (3072, 3072))
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == h["out_f16_sha256"]
+
+
+@pytest.mark.parametrize("name", ["Q4_0", "Q4_K", "Q5_K", "Q6_K"])
+def test_flux_shape_C_full_size_vs_oracle(pkg, name):
+    """configs[1]/[2] shape C (3072x12288 = 37.7 M elements) at full size, against the oracle."""
+    q = pkg.qtypes.Q[name]
+    packed = pkg.synth.make_tensor_bytes(q, (3072, 12288), seed=11, mode="signed")
+    out = pkg.dequant.dequantize(torch.from_numpy(packed).to(DEV), q, (3072, 12288))
+    want = oracle.dequant_f16(q, packed)
+    assert np.array_equal(_bits16(out), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("name", ["Q4_0", "Q5_0", "Q8_0", "Q3_K", "Q6_K", "IQ4_NL", "IQ4_XS"])
+def test_property_scale_linearity_full_size(pkg, name):
+    """Size-independent property at full BASELINE size: for the min-free formats the result is
+    d * integer, so doubling every block scale (fp16 exponent + 1) doubles every output exactly."""
+    q = pkg.qtypes.Q[name]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    n = 3072 * 12288 // bs
+    blocks = pkg.synth.make_blocks(q, n, seed=3)
+    doubled = blocks.copy()
+    (off,) = pkg.qtypes.SCALE_FIELDS[q]
+    d = doubled[:, off:off + 2].copy().view(np.uint16)
+    d += 0x0400                                                              # exponent + 1, nominal scales are normal
+    doubled[:, off:off + 2] = d.view(np.uint8)
+    a = pkg.dequant.dequantize(torch.from_numpy(blocks.reshape(-1)).to(DEV), q, (n * bs,))
+    b = pkg.dequant.dequantize(torch.from_numpy(doubled.reshape(-1)).to(DEV), q, (n * bs,))
+    # nominal d >= 1e-4 and |q| >= 1 keep d*q far from the subnormal range, so x2 is exact both ways
+    assert torch.equal(b, a * 2)
+    assert torch.equal(pkg.dequant.dequantize(torch.from_numpy(blocks.reshape(-1)).to(DEV), q, (n * bs,)), a)   # deterministic
+
+
+def test_non_default_stream_ordering(pkg):
+    """The launch goes to torch's CURRENT stream: producer copy and consumer read on a side stream."""
+    q = pkg.qtypes.Q.Q4_K
+    blocks = pkg.synth.make_blocks(q, 4096, seed=2)
+    want = oracle.dequant_f16(q, blocks).view(np.uint16)
+    host = torch.from_numpy(blocks.reshape(-1).copy()).pin_memory()
+    side = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(5):
+            dev = host.to(DEV, non_blocking=True)
+            out = pkg.dequant.dequantize(dev, q, (4096 * 256,))
+            total = out.float().sum()
+    side.synchronize()
+    assert np.array_equal(_bits16(out), want)
+    assert torch.isfinite(total)
+
+
+def test_plan_mixed_qtypes_matches_per_tensor(pkg):
+    """DequantPlan (ggq_plan_*): one launch per quant type over many tensors == per-tensor calls."""
+    Q = pkg.qtypes.Q
+    spec = [(Q.Q4_K, (96, 512)), (Q.Q6_K, (7, 256)), (Q.Q4_K, (1, 256)), (Q.Q8_0, (33, 96)), (Q.Q5_K, (64, 1024)),
+            (Q.Q4_0, (5, 32)), (Q.Q8_0, (1000, 64)), (Q.Q2_K, (3, 768)), (Q.IQ4_XS, (9, 256))]
+    items, wants, total = [], [], 0
+    for i, (q, shape) in enumerate(spec):
+        packed = pkg.synth.make_tensor_bytes(q, shape, seed=100 + i, mode="signed")
+        items.append((torch.from_numpy(packed).to(DEV), q, shape))
+        wants.append(oracle.dequant_f16(q, packed).view(np.uint16))
+        total += pkg.qtypes.algorithmic_bytes(q, shape[0] * shape[1])
+    plan = pkg.grouped.DequantPlan(items)
+    assert plan.bytes == total and plan.kernels == len({q for q, _ in spec})
+    outs = plan.launch()
+    torch.cuda.synchronize()
+    for (q, shape), out, want in zip(spec, outs, wants):
+        assert tuple(out.shape) == shape and out.dtype == torch.float16
+        assert np.array_equal(_bits16(out), want), (q, shape)
+    # mixed output dtypes in one plan: the bf16 entries equal the fused-cast path
+    plan2 = pkg.grouped.DequantPlan([it + (torch.bfloat16 if i % 2 else torch.float16,) for i, it in enumerate(items)])
+    outs2 = plan2.launch()
+    torch.cuda.synchronize()
+    for i, (out, want) in enumerate(zip(outs2, wants)):
+        ref = oracle.cast_f16_to_bf16_bits(want) if i % 2 else want
+        assert np.array_equal(_bits16(out), ref)
+    plan.close(); plan2.close()
+
+
+def test_ggml_linear_forward_is_the_reference_call_chain(pkg):
+    """GGMLOps.Linear's hot loop (ops.py:242-244): dequantize the weight on every forward, then F.linear."""
+    Q = pkg.qtypes.Q
+    for dtype in (torch.float16, torch.bfloat16, torch.float32):
+        blocks = pkg.synth.make_blocks(Q.Q5_K, 48 * 3, seed=9)                # weight 48 x 768
+        w = _carrier(pkg, blocks, Q.Q5_K, (48, 768))
+        bias_blocks = pkg.synth.make_blocks(Q.Q8_0, 2, seed=10)              # quantized bias, 64 elements... 48 used? keep 64
+        lin = pkg.ops.GGMLLinear(w)
+        x = torch.randn(5, 768, device=DEV, dtype=dtype)
+        wref = torch.from_numpy(oracle.dequant_f16(Q.Q5_K, blocks).reshape(48, 768).copy()).to(DEV).to(dtype)
+        assert torch.equal(lin(x), torch.nn.functional.linear(x, wref))
+        assert torch.equal(lin(x), lin(x))
+
+
+def test_unsupported_requests_raise(pkg):
+    dq, Q = pkg.dequant, pkg.qtypes.Q
+    data = torch.zeros(144 * 4, dtype=torch.uint8, device=DEV)
+    with pytest.raises(dq.GGQUnsupported):
+        dq.dequantize(data, Q.Q4_K, (4, 256), dtype=torch.bfloat16)          # bf16 ARITHMETIC mode: reference's job
+    with pytest.raises(dq.GGQUnsupported):
+        dq.dequantize(data, Q.IQ2_XXS, (4, 256))
+    with pytest.raises(dq.GGQUnsupported):
+        dq.dequantize(data.cpu(), Q.Q4_K, (4, 256))
+
+
+def test_c_abi_direct_call(pkg):
+    """Straight through ctypes, as INTEGRATION.md's reference-side stub does."""
+    nat, Q = pkg._native, pkg.qtypes.Q
+    lib = nat.lib()
+    blocks = pkg.synth.make_blocks(Q.Q4_1, 777, seed=4)
+    data = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    out = torch.empty(777 * 32, dtype=torch.float16, device=DEV)
+    rc = lib.ggq_dequant_f16(int(Q.Q4_1), data.data_ptr(), 777, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == nat.GGQ_OK and lib.ggq_last_hip_error() == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits16(out), oracle.dequant_f16(Q.Q4_1, blocks).view(np.uint16))

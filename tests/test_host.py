@@ -1,0 +1,266 @@
+"""Host-side logic that needs no GPU: tables, synthetic blocks, the C-ABI library's exports and
+argument checking, the mirrored dequant interface's dispatch / error behaviour, sharding,
+manifests, and install() in front of the real reference modules (when /root/reference exists)."""
+import ctypes
+import importlib.util
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import reference
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_qtype_tables_agree_with_oracle(pkg):
+    qt = pkg.qtypes
+    for q in qt.HIP_QTYPES + (qt.Q.BF16,):
+        assert oracle.geometry(q) == qt.block_geometry(q), q
+    # algorithmic bytes of BASELINE.md section 3
+    assert qt.algorithmic_bytes(qt.Q.Q4_K, 3072 * 3072) == 24_182_784
+    assert qt.algorithmic_bytes(qt.Q.Q6_K, 3072 * 12288) == 106_463_232
+    assert qt.algorithmic_bytes(qt.Q.Q8_0, 4096 * 4096) == 51_380_224
+
+
+def test_synth_is_deterministic_and_sanitised(pkg):
+    q = pkg.qtypes.Q.Q4_K
+    a = pkg.synth.make_blocks(q, 100, seed=3)
+    b = pkg.synth.make_blocks(q, 100, seed=3)
+    assert np.array_equal(a, b) and a.shape == (100, 144)
+    d = a[:, 0:2].copy().view(np.float16).reshape(-1)
+    assert np.all((d >= 1e-4 * 0.99) & (d <= 2e-3 * 1.01))
+    assert not np.array_equal(a, pkg.synth.make_blocks(q, 100, seed=4))
+    assert pkg.synth.make_blocks(q, 0).shape == (0, 144)
+    with pytest.raises(ValueError):
+        pkg.synth.n_blocks_for(q, 100)
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "ggq.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ggq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    """The C-ABI library loads and exports everything include/ggq.h declares (no compute calls)."""
+    nat = pkg._native
+    assert os.path.exists(nat.LIB_PATH), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(nat.LIB_PATH)
+    declared = _declared_symbols()
+    assert set(declared) == set(nat.SYMBOLS), (declared, sorted(nat.SYMBOLS))
+    for name in declared:
+        getattr(L, name)
+    lib = nat.lib()
+    assert lib.ggq_abi_version() == nat.ABI_VERSION
+
+
+def test_c_abi_queries_and_argument_checks(pkg):
+    """Pure host-side entry points and the argument validation that runs before any launch."""
+    nat, qt = pkg._native, pkg.qtypes
+    lib = nat.lib()
+    for q in qt.HIP_QTYPES:
+        assert lib.ggq_supported(int(q)) == 1
+        assert (lib.ggq_block_size(int(q)), lib.ggq_type_size(int(q))) == qt.block_geometry(q)
+    for bad in (0, 1, 9, 15, 16, 30, 99, -1):      # F32, F16, Q8_1, Q8_K, IQ2_XXS, BF16, junk
+        assert lib.ggq_supported(bad) == 0 and lib.ggq_block_size(bad) == 0 and lib.ggq_type_size(bad) == 0
+    assert lib.ggq_strerror(0) == b"ok" and b"aligned" in lib.ggq_strerror(nat.GGQ_ERR_ALIGN)
+    q4k = int(qt.Q.Q4_K)
+    assert lib.ggq_dequant(99, 16, 1, 16, 0, None) == nat.GGQ_ERR_QTYPE
+    assert lib.ggq_dequant(q4k, 16, 1, 16, 7, None) == nat.GGQ_ERR_ARG          # bad out dtype
+    assert lib.ggq_dequant(q4k, None, 1, 16, 0, None) == nat.GGQ_ERR_ARG         # NULL packed
+    assert lib.ggq_dequant(q4k, 24, 1, 32, 0, None) == nat.GGQ_ERR_ALIGN         # packed % 16 != 0
+    assert lib.ggq_dequant(q4k, 32, 1, 8, 0, None) == nat.GGQ_ERR_ALIGN          # out % 16 != 0
+    assert lib.ggq_dequant(q4k, None, 0, None, 0, None) == nat.GGQ_OK            # empty tensor: no-op
+    assert lib.ggq_dequant_f16(99, 16, 1, 16, None) == nat.GGQ_ERR_QTYPE
+    plan = ctypes.c_void_p()
+    bad = (nat.ggq_desc * 1)(nat.ggq_desc(99, 0, 16, 16, 1))
+    assert lib.ggq_plan_create(bad, 1, ctypes.byref(plan)) == nat.GGQ_ERR_QTYPE and not plan.value
+    assert lib.ggq_plan_launch(None, None) == nat.GGQ_ERR_ARG
+    assert lib.ggq_plan_bytes(None) == 0
+    with pytest.raises(nat.GGQNativeError, match="aligned"):
+        nat.check(nat.GGQ_ERR_ALIGN, "x")
+
+
+def test_missing_extension_fails_loudly(pkg, monkeypatch):
+    nat = pkg._native
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", os.path.join(ROOT, "does", "not", "exist.so"))
+    with pytest.raises(nat.GGQNativeError, match="no CPU or torch fallback"):
+        nat.lib()
+
+
+def test_fma_guard_regex(pkg):
+    nat = pkg._native
+    nat.check_no_fma("v_pk_mul_f16 v1, v2, v3\nv_pk_add_f16 v1, v1, v4 neg_lo:[0,1]\nv_mad_u32_u24 v0, v1, v2, v3\n")
+    for bad in ("v_pk_fma_f16 v1, v2, v3, v4", "v_fma_f16 v1, v2, v3, v4", "v_fma_mix_f32 v1, v2, v3, v4", "v_fmac_f16_e32 v1, v2, v3"):
+        with pytest.raises(nat.GGQNativeError):
+            nat.check_no_fma(bad)
+
+
+class _Carrier:
+    """Anything with .data/.tensor_type/.tensor_shape is what dequantize_tensor reads (dequant.py:16-17)."""
+
+    def __init__(self, data, tensor_type, tensor_shape):
+        self.data, self.tensor_type, self.tensor_shape, self.shape = data, tensor_type, tensor_shape, tensor_shape
+
+    def to(self, *a, **k):
+        return self.data.to(*a, **k)
+
+
+def test_dispatch_and_error_behaviour_on_cpu(pkg, golden_dir):
+    dq, Q = pkg.dequant, pkg.qtypes.Q
+    assert dq.is_torch_compatible(None) and not dq.is_quantized(None)
+    w = torch.randn(4, 4)
+    assert dq.is_torch_compatible(w) and not dq.is_quantized(w)          # no tensor_type attr
+    f16 = _Carrier(torch.randn(4, 4).half(), Q.F16, torch.Size((4, 4)))
+    assert not dq.is_quantized(f16)
+    assert dq.dequantize_tensor(f16, torch.float32).dtype == torch.float32   # passthrough .to(dtype), dequant.py:19-20
+    q = _Carrier(torch.zeros(144, dtype=torch.uint8), Q.Q4_K, torch.Size((1, 256)))
+    assert dq.is_quantized(q)
+    with pytest.raises(dq.GGQUnsupported, match="cpu"):                  # no CPU fallback in this package
+        dq.dequantize_tensor(q, torch.float16)
+    with pytest.raises(dq.GGQUnsupported):
+        dq.dequantize(q.data, Q.Q4_K, (1, 256))
+    with pytest.raises(dq.GGQUnsupported, match="float32"):
+        dq.dequantize(q.data, Q.Q4_K, (1, 256), dtype=torch.float32)
+    with pytest.raises(dq.GGQUnsupported, match="float32"):
+        dq.dequantize_tensor(q, torch.float32, dequant_dtype="target")
+    odd = _Carrier(torch.zeros(66, dtype=torch.uint8), Q.IQ2_XXS, torch.Size((256,)))
+    with pytest.raises(dq.GGQUnsupported, match="IQ2_XXS"):
+        dq.dequantize_tensor(odd, torch.float16)
+    assert set(dq.dequantize_functions) == set(pkg.qtypes.HIP_QTYPES) | {Q.BF16}
+    assert dq.dequantize_functions[Q.Q6_K].__name__ == "dequantize_blocks_Q6_K"
+    with pytest.raises(ValueError):
+        dq.dequantize_functions[Q.Q6_K](torch.zeros(1, 210, dtype=torch.uint8), 256, 144)
+    # BF16 "blocks" are a bit reinterpretation: served by one torch op wherever the data lives
+    g = np.load(os.path.join(golden_dir, "BF16.npz"))
+    out = dq.dequantize(torch.from_numpy(g["blocks"].copy()), Q.BF16, (4096,))
+    assert out.dtype == torch.float32
+    assert np.array_equal(out.numpy().view(np.uint32), g["out_f32"].reshape(-1))
+
+
+def test_ggml_tensor_carries_attrs(pkg):
+    T, Q = pkg.ops.GGMLTensor, pkg.qtypes.Q
+    t = T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256))
+    assert t.shape == torch.Size((2, 256)) and t.size() == torch.Size((288,))
+    u = t.to(torch.device("cpu"))
+    assert isinstance(u, T) and u.tensor_type == Q.Q4_K and u.shape == torch.Size((2, 256))
+    assert t.clone() is t and t.detach() is t
+    assert pkg.dequant.is_quantized(t)
+
+
+def test_partition_covers_and_balances(pkg):
+    sh, man = pkg.sharding, pkg.manifests
+    for manifest in (man.flux_dev(), man.sd35_t5(), man.flux_linear_pool(12, 3)):
+        for world in (1, 2, 3, 4, 8):
+            bins = sh.partition(manifest, world)
+            flat = sorted(i for b in bins for i in b)
+            assert flat == list(range(len(manifest)))
+            if len(manifest) >= 100:                                   # whole tensors only: small lists cannot balance
+                assert sh.imbalance(manifest, world) < 1.02
+            assert bins == sh.partition(manifest, world)            # deterministic: ranks agree without talking
+            assert [manifest[i] for i in bins[world - 1]] == sh.shard(manifest, world - 1, world)
+    assert sh.partition([], 2) == [[], []]
+    with pytest.raises(ValueError):
+        sh.partition(man.flux_dev(), 0)
+
+
+def test_manifests_are_well_formed(pkg):
+    qt, man = pkg.qtypes, pkg.manifests
+    for manifest in (man.flux_dev(), man.flux_dev("Q8_0"), man.sd35_t5(), man.flux_linear_pool(qt.Q.Q6_K)):
+        names = [e[0] for e in manifest]
+        assert len(set(names)) == len(names)
+        for _, q, shape in manifest:
+            bs, _ = qt.block_geometry(q)
+            assert q in qt.HIP_QTYPES and len(shape) == 2
+            assert shape[1] % bs == 0, (q, shape)          # rows are whole blocks (lcpp.patch:227-253)
+    flux = man.flux_dev()
+    n_el = sum(a * b for _, _, (a, b) in flux)
+    assert 11.5e9 < n_el < 12.1e9                          # FLUX.1-dev: ~11.9 B parameters in the blocks
+
+
+# ---------------------------------------------------------------- install() in front of the reference
+
+def _fake_comfy():
+    """The comfy symbols reference ops.py touches."""
+    comfy = types.ModuleType("comfy")
+    ops = types.ModuleType("comfy.ops")
+
+    class CastWeightBiasOp:
+        comfy_cast_weights = False
+
+    class manual_cast:
+        class Linear(torch.nn.Linear, CastWeightBiasOp):
+            def forward_comfy_cast_weights(self, x):
+                return torch.nn.functional.linear(x, self.weight.to(x.dtype), self.bias)
+
+            def forward(self, *a, **k):
+                return self.forward_comfy_cast_weights(*a, **k)
+
+        class Conv2d(torch.nn.Conv2d, CastWeightBiasOp):
+            pass
+
+        class Embedding(torch.nn.Embedding, CastWeightBiasOp):
+            pass
+
+        class LayerNorm(torch.nn.LayerNorm, CastWeightBiasOp):
+            pass
+
+        class GroupNorm(torch.nn.GroupNorm, CastWeightBiasOp):
+            pass
+
+    ops.manual_cast = manual_cast
+    ops.cast_to = lambda t, dtype, device, non_blocking=False, copy=False: t.to(device=device, dtype=dtype)
+    mm = types.ModuleType("comfy.model_management")
+    mm.device_supports_non_blocking = lambda device: False
+    lora = types.ModuleType("comfy.lora")
+    lora.calculate_weight = lambda patches, weight, key, *a: weight
+    comfy.ops, comfy.model_management, comfy.lora = ops, mm, lora
+    return {"comfy": comfy, "comfy.ops": ops, "comfy.model_management": mm, "comfy.lora": lora}
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
+    """With install() applied, the reference's own GGMLOps.Linear still runs end to end; CPU-resident
+    weights keep flowing through the reference's original functions (the HIP path only takes GPU data)."""
+    reference.ensure_gguf()
+    for k, v in _fake_comfy().items():
+        monkeypatch.setitem(sys.modules, k, v)
+    pk = types.ModuleType("refpkg")
+    pk.__path__ = [reference.REFERENCE_DIR]
+    monkeypatch.setitem(sys.modules, "refpkg", pk)
+    mods = {}
+    for name in ("dequant", "ops"):
+        spec = importlib.util.spec_from_file_location(f"refpkg.{name}", os.path.join(reference.REFERENCE_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        monkeypatch.setitem(sys.modules, f"refpkg.{name}", m)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    rd, ro = mods["dequant"], mods["ops"]
+    Q = pkg.qtypes.Q
+    blocks = pkg.synth.make_blocks(Q.Q4_K, 8 * 2, seed=21)                 # weight 8 x 512
+    weight = ro.GGMLTensor(torch.from_numpy(blocks.reshape(-1).copy()), tensor_type=Q.Q4_K, tensor_shape=torch.Size((8, 512)))
+    lin = ro.GGMLOps.Linear(512, 8)
+    lin.weight, lin.bias = torch.nn.Parameter(weight, requires_grad=False), None
+    x = torch.randn(3, 512)
+    before = lin(x)
+    orig = pkg.install.install(rd, ro)
+    try:
+        assert rd.dequantize is not orig["dequantize"] and ro.dequantize_tensor is rd.dequantize_tensor
+        after = lin(x)                                                        # CPU weight -> reference path
+        assert torch.equal(before, after)
+        want = torch.from_numpy(oracle.dequant_f16(Q.Q4_K, blocks).reshape(8, 512).copy()).float()
+        assert torch.equal(after, torch.nn.functional.linear(x, want))
+        # an out-of-scope arithmetic mode also falls through to the reference, not to an error
+        w32 = rd.dequantize_tensor(weight, torch.float32, dequant_dtype=torch.float32)
+        assert w32.dtype == torch.float32
+        assert np.array_equal(w32.numpy().reshape(-1), oracle.dequant_f32(Q.Q4_K, blocks))
+    finally:
+        pkg.install.uninstall(rd)
+    assert rd.dequantize is orig["dequantize"] and ro.dequantize_tensor is orig["dequantize_tensor"]
