@@ -365,6 +365,35 @@ static void formats()
     }
 }
 
+// A short, fixed sequence for rocprofv3 --pmc passes: streams of KNOWN size (to calibrate
+// FETCH_SIZE / WRITE_SIZE on this access pattern) followed by the shipped kernels on the bench pool.
+static void pmc_sequence()
+{
+    const uint64_t bytes = 1ull << 30;
+    ggq::u32x4 *a, *b;
+    HIP_CHECK(hipMalloc(&a, bytes)); HIP_CHECK(hipMalloc(&b, bytes));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(a), bytes / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    const uint64_t n16 = bytes / 16;
+    printf("PMC known sizes: k_copy16/k_copy16nt read %llu B + write %llu B; k_fill16/k_fill16nt write %llu B\n", (unsigned long long)bytes, (unsigned long long)bytes, (unsigned long long)bytes);
+    for (int i = 0; i < 3; i++) { k_copy16<<<262144, 256>>>(a, b, n16); k_copy16nt<<<262144, 256>>>(a, b, n16); k_fill16<<<262144, 256>>>(b, n16); k_fill16nt<<<262144, 256>>>(b, n16); }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
+    for (int qi : {7, 0, 9, 4}) {
+        Pool P = make_pool(QTS[qi], 8);
+        std::vector<ggq_desc> descs;
+        for (auto& d : P.descs) descs.push_back(ggq_desc{QTS[qi].id, GGQ_OUT_F16, d.packed, d.out, d.n_blocks});
+        ggq_plan* plan = nullptr;
+        if (ggq_plan_create(descs.data(), (uint32_t)descs.size(), &plan)) { printf("plan_create failed\n"); continue; }
+        printf("PMC %s pool: packed read %llu B + fp16 write %llu B = %llu B per launch\n", QTS[qi].name, (unsigned long long)(P.elements / P.bs * P.ts),
+               (unsigned long long)P.out_bytes, (unsigned long long)ggq_plan_bytes(plan));
+        for (int i = 0; i < 5; i++) ggq_plan_launch(plan, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        ggq_plan_destroy(plan);
+        free_pool(P);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -375,5 +404,6 @@ int main(int argc, char** argv)
     if (what == "ceil" || what == "all") ceilings();
     if (what == "formats" || what == "all") formats();
     if (what == "variants" || what == "all") variants();
+    if (what == "pmc") pmc_sequence();
     return rc ? 1 : 0;
 }
