@@ -11,14 +11,22 @@ namespace {
 
 using namespace ggq;
 
-// Launch geometry chosen on MI355X (DESIGN.md "Tuning", profiles/r01_microbench_*): one group of
-// G blocks per wavefront, non-temporal loads and stores (the packed bytes are read once and the
-// dense tensor is not re-read by this kernel), 4 waves per workgroup.
+// Launch geometry, chosen by interleaved A/B runs on MI355X (DESIGN.md section 4 "Tuning",
+// profiles/r01_microbench_*): one group of 2048 output elements per wavefront, non-temporal stores.
+//   * default: the group's packed bytes are staged through a wave-private LDS slice with wide
+//     non-temporal loads; one wave per workgroup (1-3 % better than 4 for the 4-bit formats);
+//   * DIRECT for the formats where it measured faster -- Q2_K and Q3_K (smallest blocks: 7.1-7.2 TB/s
+//     vs 6.0 staged) and Q5_0 (2-byte-aligned blocks whose staged LDS reads replay): every lane reads
+//     its few bytes straight from global memory through the vector L1, row by row.
 template <class F> struct Tune {
-    static constexpr int G = (F::BS == 256) ? 8 : 64;   // 2048 output elements = 4 KiB fp16 per group
+    static constexpr int G = (F::BS == 256) ? 8 : 64;
+    static constexpr bool DIRECT = false;
     static constexpr bool NTL = true, NTS = true;
-    static constexpr int WAVES = 4;
+    static constexpr int WAVES = 1;
 };
+template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
+template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
+template <> struct Tune<FmtQ5_0> { static constexpr int G = 64; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
 
 thread_local int t_last_hip = 0;
 constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
@@ -34,7 +42,7 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
     return hipGetLastError();
 }
 
@@ -45,7 +53,7 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t 
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
     return hipGetLastError();
 }
 

@@ -397,7 +397,15 @@ GGQ_DEV void wave_sync()
 //   F      block format            G      blocks per group
 //   OUT    output dtype            NTL/NTS  non-temporal loads / stores
 //   WAVES  wavefronts per workgroup (they share nothing but the LDS allocation)
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+// at most THR+1 store rows of a wave in flight (THR < 0: no throttle)
+template <int THR>
+GGQ_DEV void store_throttle()
+{
+    // s_waitcnt simm16 on gfx9: vmcnt = [3:0] | [15:14], expcnt = [6:4], lgkmcnt = [11:8]
+    if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
+}
+
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -454,13 +462,33 @@ struct Engine {
                 const u32x4 v = F::chunk(slice + a + bl * TS, j);
                 store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
             }
+            if (s + 1 < NCH) store_throttle<THR>();
+        }
+    }
+
+    // DIRECT: no LDS staging -- every lane reads the few bytes its chunk needs straight from
+    // global memory (the same F::chunk code, pointed at the packed bytes).  A wave-row of 64 chunks
+    // touches 3-5 cache lines; neighbouring lanes share them through the vector L1.
+    template <bool FULL>
+    GGQ_DEV static void body_direct(const Work& w, int lane)
+    {
+        const uint64_t b0 = w.lg * (uint64_t)G;
+#pragma unroll
+        for (int s = 0; s < NCH; s++) {
+            const int chunk = lane + 64 * s;
+            const int bl = chunk / CPB, j = chunk % CPB;
+            const uint64_t gb = b0 + (uint64_t)bl;
+            if (FULL || gb < w.n_blocks) {
+                const u32x4 v = F::chunk(w.packed + gb * (uint64_t)TS, j);
+                store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
+            }
         }
     }
 
     template <class Locate>
     GGQ_DEV static void run(uint64_t total_groups, Locate locate)
     {
-        __shared__ __attribute__((aligned(16))) uint8_t smem[WAVES * SLICE];
+        __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : WAVES * SLICE];
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int lane = (int)(threadIdx.x & 63);
         uint32_t bid = blockIdx.x;
@@ -472,25 +500,41 @@ struct Engine {
         }
         const uint64_t g = (uint64_t)bid * WAVES + (uint64_t)wave;
         if (g >= total_groups) return;
-        const Work w = locate(g);
-        uint8_t* slice = smem + wave * SLICE;
-        if ((w.lg + 1) * (uint64_t)G <= w.n_blocks) body<true>(slice, w, lane);
-        else body<false>(slice, w, lane);
+        const Work w0 = locate(g);                       // lg counts units of R*G blocks
+        uint8_t* slice = smem + (DIRECT ? 0 : wave * SLICE);
+        // R > 1: the wave walks R consecutive groups strictly one after the other -- load, unpack,
+        // store, wait for the store -- so it never has more than one group's traffic in flight.
+#pragma unroll 1
+        for (int r = 0; r < R; r++) {
+            Work w = w0;
+            w.lg = w0.lg * (uint64_t)R + (uint64_t)r;
+            if (r > 0 && w.lg * (uint64_t)G >= w.n_blocks) break;
+            const bool full = (w.lg + 1) * (uint64_t)G <= w.n_blocks;
+            if constexpr (DIRECT) {
+                if (full) body_direct<true>(w, lane); else body_direct<false>(w, lane);
+            } else {
+                if (full) body<true>(slice, w, lane); else body<false>(slice, w, lane);
+            }
+            if (r + 1 < R) {
+                store_throttle<0>();
+                wave_sync();
+            }
+        }
     }
 };
 
 // one tensor, descriptor by value
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
 __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD>::run(total_groups, [&](uint64_t g) { return Work{d.packed, d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) { return Work{d.packed, d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD>::run(total_groups, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) {
         uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;

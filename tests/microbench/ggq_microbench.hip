@@ -265,13 +265,13 @@ static Pool make_pool(const QT& q, int pairs)
 static void free_pool(Pool& P) { HIP_CHECK(hipFree(P.packed)); HIP_CHECK(hipFree(P.out)); }
 
 // parity of an arbitrary instantiation (variants other than the shipped one) vs the oracle
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD>
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT = false, int THR = -1, int R = 1>
 static bool check_variant()
 {
     const QT* q = nullptr;
     for (const QT& x : QTS) if (x.id == F::ID) q = &x;
     bool ok = true;
-    for (uint64_t n : {(uint64_t)1, (uint64_t)(G - 1 > 0 ? G - 1 : 1), (uint64_t)G, (uint64_t)(3 * G + 1), (uint64_t)(F::BS == 32 ? 20011 : 2503)}) {
+    for (uint64_t n : {(uint64_t)1, (uint64_t)(G - 1 > 0 ? G - 1 : 1), (uint64_t)G, (uint64_t)(3 * G + 1), (uint64_t)(G * R), (uint64_t)(G * R + 1), (uint64_t)(F::BS == 32 ? 20011 : 2503)}) {
         std::vector<uint8_t> packed; make_blocks(*q, n, (int)(n & 1), packed);
         std::vector<uint16_t> want(n * F::BS), got(n * F::BS);
         ggq_oracle_dequant_f16(F::ID, packed.data(), n, want.data());
@@ -279,8 +279,8 @@ static bool check_variant()
         HIP_CHECK(hipMalloc(&dp, packed.size())); HIP_CHECK(hipMalloc(&dout, n * F::BS * 2 + 256));
         HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
-        const uint64_t groups = (n + G - 1) / G;
-        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD>), dim3((uint32_t)((groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+        const uint64_t groups = (n + G * R - 1) / (G * R);
+        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3((uint32_t)((groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
                            ggq::Desc{dp, dout, n, 0}, groups);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
@@ -292,10 +292,10 @@ static bool check_variant()
     return ok;
 }
 
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD>
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT = false, int THR = -1>
 static void time_variant(const char* name, Pool& P, Timer& T)
 {
-    const bool ok = check_variant<F, G, NTL, NTS, WAVES, XCD>();
+    const bool ok = check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR>();
     std::vector<ggq::Desc> d = P.descs;
     uint64_t groups = 0;
     for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
@@ -303,42 +303,263 @@ static void time_variant(const char* name, Pool& P, Timer& T)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     double med, mn;
-    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups); }, 3, 31, med, mn);
+    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups); }, 3, 31, med, mn);
     const double bytes = (double)P.elements * (2.0 + (double)P.ts / P.bs);
-    printf("VAR %-6s G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
+    printf("VAR %-6s %s thr=%-2d G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, DIRECT ? "direct" : "lds   ", THR, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
            (unsigned long long)blocks, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6, ok ? "ok" : "MISMATCH");
     fflush(stdout);
     HIP_CHECK(hipFree(dt));
 }
 
 template <class F, int G>
-static void sweep_w(const char* name, Pool& P, Timer& T)
-{
-    time_variant<F, G, true, true, 1, false>(name, P, T);
-    time_variant<F, G, true, true, 2, false>(name, P, T);
-    time_variant<F, G, true, true, 4, false>(name, P, T);
-    time_variant<F, G, true, true, 8, false>(name, P, T);
-}
-
-template <class F, int GA, int GB, int GC>
-static void sweep(const char* name, int qi)
+static void sweep_thr(const char* name, int qi)
 {
     Timer T;
     Pool P = make_pool(QTS[qi], 12);
-    sweep_w<F, GA>(name, P, T); sweep_w<F, GB>(name, P, T); sweep_w<F, GC>(name, P, T);
-    time_variant<F, GC, true, true, 4, false>(name, P, T);     // again (drift check)
+    time_variant<F, G, true, true, 4, false, false, -1>(name, P, T);
+    time_variant<F, G, true, true, 4, false, false, 0>(name, P, T);
+    time_variant<F, G, true, true, 4, false, false, 1>(name, P, T);
+    time_variant<F, G, true, true, 4, false, false, 2>(name, P, T);
+    time_variant<F, 2 * G, true, true, 4, false, false, 0>(name, P, T);
+    time_variant<F, 2 * G, true, true, 4, false, false, 1>(name, P, T);
+    time_variant<F, 4 * G, true, true, 4, false, false, 0>(name, P, T);
+    time_variant<F, G, true, true, 8, false, false, 0>(name, P, T);
+    time_variant<F, G, true, true, 2, false, false, 0>(name, P, T);
+    time_variant<F, G, true, false, 4, false, false, 0>(name, P, T);
+    time_variant<F, G, true, true, 4, false, false, -1>(name, P, T);
     free_pool(P);
 }
 
 static void variants()
 {
-    sweep<ggq::FmtQ4_K, 2, 4, 8>("Q4_K", 7);
-    sweep<ggq::FmtQ6_K, 2, 4, 8>("Q6_K", 9);
-    sweep<ggq::FmtQ2_K, 2, 4, 8>("Q2_K", 5);
-    sweep<ggq::FmtQ3_K, 2, 4, 8>("Q3_K", 6);
-    sweep<ggq::FmtQ4_0, 16, 32, 64>("Q4_0", 0);
-    sweep<ggq::FmtQ5_0, 16, 32, 64>("Q5_0", 2);
-    sweep<ggq::FmtQ8_0, 16, 32, 64>("Q8_0", 4);
+    sweep_thr<ggq::FmtQ4_K, 8>("Q4_K", 7);
+    sweep_thr<ggq::FmtQ2_K, 8>("Q2_K", 5);
+    sweep_thr<ggq::FmtQ6_K, 8>("Q6_K", 9);
+    sweep_thr<ggq::FmtQ4_0, 64>("Q4_0", 0);
+    sweep_thr<ggq::FmtQ8_0, 64>("Q8_0", 4);
+}
+
+// ---- traffic skeletons: the dequant kernels' exact memory shape with no LDS and no arithmetic.
+// One wave = LOAD_UNITS 16-B loads (contiguous, like a group's packed bytes) then NST 1-KiB store rows.
+// DEP: 0 = no loads at all, 1 = the stores depend on the loads (as in the real kernel),
+//      2 = loads issued but the stores do not wait for them.
+template <int NST, int LOAD_UNITS, int DEP, bool NT, int WAVES, int THR = -1>
+__global__ __launch_bounds__(WAVES * 64) void k_skel(const ggq::u32x4* __restrict__ in, ggq::u32x4* __restrict__ out, uint64_t n_waves)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * WAVES + wave;
+    if (w >= n_waves) return;
+    ggq::u32x4 acc{(uint32_t)lane, 1, 2, 3};
+    constexpr int NU = (LOAD_UNITS + 63) / 64;
+    ggq::u32x4 ld[NU > 0 ? NU : 1];
+    if (DEP) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int idx = lane + 64 * u;
+            ld[u] = ggq::u32x4{0, 0, 0, 0};
+            if (idx < LOAD_UNITS) ld[u] = NT ? __builtin_nontemporal_load(in + w * LOAD_UNITS + idx) : in[w * LOAD_UNITS + idx];
+        }
+    }
+    if (DEP == 1) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) acc.x ^= (uint32_t)__builtin_amdgcn_readfirstlane((int)ld[u].y) + ld[u].x;
+    }
+#pragma unroll
+    for (int s = 0; s < NST; s++) {
+        ggq::u32x4 v = acc; v.y += s;
+        if (NT) __builtin_nontemporal_store(v, out + (w * NST + s) * 64 + lane); else out[(w * NST + s) * 64 + lane] = v;
+        if (s + 1 < NST) ggq::store_throttle<THR>();
+    }
+    if (DEP == 2) {
+#pragma unroll
+        for (int u = 0; u < NU; u++) asm volatile("" ::"v"(ld[u].x));
+    }
+}
+
+template <int NST, int LOAD_UNITS, int DEP, bool NT, int WAVES, int THR = -1>
+static void run_skel(Timer& T, ggq::u32x4* in, ggq::u32x4* out, uint64_t out_bytes)
+{
+    const uint64_t n_waves = out_bytes / (NST * 1024ull);
+    const uint64_t blocks = (n_waves + WAVES - 1) / WAVES;
+    double med, mn;
+    T.run([&] { hipLaunchKernelGGL((k_skel<NST, LOAD_UNITS, DEP, NT, WAVES, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, in, out, n_waves); }, 3, 21, med, mn);
+    const double bytes = (double)n_waves * (NST * 1024.0 + (DEP ? LOAD_UNITS * 16.0 : 0.0));
+    printf("SKEL thr=%-2d store_rows=%d load_units=%-3d dep=%d nt=%d waves=%d  out %.2f GB  %7.3f ms  %8.1f GB/s median  best %8.1f   (writes alone %.1f GB/s)\n", THR, NST, DEP ? LOAD_UNITS : 0, DEP, (int)NT, WAVES,
+           out_bytes / 1e9, med, bytes / med / 1e6, bytes / mn / 1e6, n_waves * NST * 1024.0 / med / 1e6);
+    fflush(stdout);
+}
+
+static void skeletons()
+{
+    Timer T;
+    const uint64_t out_bytes = 1132462080ull;             // the 12-pair pool's fp16 output
+    ggq::u32x4 *in, *out;
+    HIP_CHECK(hipMalloc(&in, out_bytes)); HIP_CHECK(hipMalloc(&out, out_bytes));   // in: >= 288/1024 of out for every shape below
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(in), out_bytes / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    // pure writes: rows per wave x throttle
+    run_skel<1, 0, 0, true, 4>(T, in, out, out_bytes);
+    run_skel<4, 0, 0, true, 4>(T, in, out, out_bytes);      run_skel<4, 0, 0, true, 4, 0>(T, in, out, out_bytes);
+    run_skel<4, 0, 0, true, 4, 1>(T, in, out, out_bytes);   run_skel<16, 0, 0, true, 4, 0>(T, in, out, out_bytes);
+    run_skel<16, 0, 0, true, 4, 1>(T, in, out, out_bytes);  run_skel<64, 0, 0, true, 4, 0>(T, in, out, out_bytes);
+    // Q4_K-shaped: 72 units (1152 B) in, 4 rows (4 KiB) out
+    run_skel<4, 72, 1, true, 4>(T, in, out, out_bytes);     run_skel<4, 72, 1, true, 4, 0>(T, in, out, out_bytes);
+    run_skel<4, 72, 1, true, 4, 1>(T, in, out, out_bytes);  run_skel<8, 144, 1, true, 4, 0>(T, in, out, out_bytes);
+    run_skel<16, 288, 1, true, 4, 0>(T, in, out, out_bytes);
+    // Q2_K-shaped (42 units), Q6_K-shaped (105)
+    run_skel<4, 42, 1, true, 4, 0>(T, in, out, out_bytes);  run_skel<4, 105, 1, true, 4, 0>(T, in, out, out_bytes);
+    run_skel<4, 72, 1, true, 4>(T, in, out, out_bytes);
+    HIP_CHECK(hipFree(in)); HIP_CHECK(hipFree(out));
+}
+
+// ---- counter study: a fixed sequence of kernel variants for rocprofv3 --pmc passes
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT, int THR>
+static void launch3(Pool& P)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    const uint64_t blocks = (groups + WAVES - 1) / WAVES;
+    for (int i = 0; i < 3; i++)
+        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(dt));
+}
+
+static void pmc2_sequence()
+{
+    { Pool P = make_pool(QTS[5], 12);
+      launch3<ggq::FmtQ2_K, 8, true, true, 4, false, false, -1>(P);
+      launch3<ggq::FmtQ2_K, 8, true, true, 4, false, true, -1>(P);
+      free_pool(P); }
+    { Pool P = make_pool(QTS[7], 12);
+      launch3<ggq::FmtQ4_K, 8, true, true, 4, false, false, -1>(P);
+      launch3<ggq::FmtQ4_K, 8, true, true, 4, false, true, -1>(P);
+      free_pool(P); }
+    const uint64_t out_bytes = 1132462080ull;
+    ggq::u32x4 *in, *out;
+    HIP_CHECK(hipMalloc(&in, out_bytes)); HIP_CHECK(hipMalloc(&out, out_bytes));
+    for (int i = 0; i < 3; i++) {
+        hipLaunchKernelGGL((k_skel<1, 0, 0, true, 4, -1>), dim3((uint32_t)(out_bytes / 1024 / 4)), dim3(256), 0, nullptr, in, out, out_bytes / 1024);
+        hipLaunchKernelGGL((k_skel<4, 0, 0, true, 4, -1>), dim3((uint32_t)(out_bytes / 4096 / 4)), dim3(256), 0, nullptr, in, out, out_bytes / 4096);
+        hipLaunchKernelGGL((k_skel<4, 72, 1, true, 4, -1>), dim3((uint32_t)(out_bytes / 4096 / 4)), dim3(256), 0, nullptr, in, out, out_bytes / 4096);
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(in)); HIP_CHECK(hipFree(out));
+}
+
+// ---- interleaved A/B: N variants x R rounds in one process, round-robin, so clock / thermal drift
+// hits every variant equally (cdna_hip_programming.md 5.4 rule 24).  Reports the median over rounds.
+#include <functional>
+struct ABVariant { std::string name; std::function<void()> launch; double bytes; std::vector<double> ms; bool ok; };
+struct AB {
+    std::vector<ABVariant> v;
+    std::vector<void*> to_free;
+    void run(int rounds, int launches)
+    {
+        Timer T;
+        for (int w = 0; w < 40; w++) for (auto& x : v) x.launch();        // sustained warm-up (~50-100 ms)
+        HIP_CHECK(hipDeviceSynchronize());
+        for (int r = 0; r < rounds; r++) {
+            for (size_t k = 0; k < v.size(); k++) {
+                auto& x = v[(k + r) % v.size()];                           // rotate the order every round
+                HIP_CHECK(hipEventRecord(T.a, nullptr));
+                for (int i = 0; i < launches; i++) x.launch();
+                HIP_CHECK(hipEventRecord(T.b, nullptr));
+                HIP_CHECK(hipEventSynchronize(T.b));
+                float t; HIP_CHECK(hipEventElapsedTime(&t, T.a, T.b));
+                x.ms.push_back(t / launches);
+            }
+        }
+        for (auto& x : v) {
+            std::sort(x.ms.begin(), x.ms.end());
+            const double med = x.ms[x.ms.size() / 2], lo = x.ms[x.ms.size() / 10], hi = x.ms[x.ms.size() * 9 / 10];
+            printf("AB %-44s %7.4f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)   p10..p90 %8.1f .. %8.1f GB/s  parity=%s\n", x.name.c_str(), med, x.bytes / med / 1e6,
+                   x.bytes / med / 1e6 / 80.0, x.bytes / hi / 1e6, x.bytes / lo / 1e6, x.ok ? "ok" : "MISMATCH");
+        }
+        fflush(stdout);
+        for (void* p : to_free) HIP_CHECK(hipFree(p));
+    }
+};
+
+template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT, int THR, int R = 1>
+static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G * R - 1) / (G * R); }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    ab.to_free.push_back(dt);
+    const uint32_t blocks = (uint32_t)((groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
+    char buf[128];
+    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, THR, dyn_lds / 1024);
+    if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R>()});
+}
+
+template <class F, int G>
+static void ab_format(const char* name, int qi)
+{
+    Pool P = make_pool(QTS[qi], 12);
+    AB ab;
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P);
+    ab_add<F, G, true, true, 4, false, true, -1>(ab, name, P);
+    ab_add<F, G, false, true, 4, false, true, -1>(ab, name, P);
+    ab_add<F, G, true, true, 4, false, false, 0>(ab, name, P);
+    ab_add<F, G, true, true, 2, false, false, -1>(ab, name, P);
+    ab_add<F, G, true, true, 1, false, false, -1>(ab, name, P);
+    ab.run(20, 8);
+    free_pool(P);
+}
+
+template <class F, int G>
+static void ab_occupancy(const char* name, int qi)
+{
+    Pool P = make_pool(QTS[qi], 12);
+    AB ab;
+    // dynamic LDS that is never touched: it only caps the workgroups (x4 waves) resident per CU
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 0);            // 8 WG = 32 waves / CU
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 18 * 1024);    // 6 WG = 24 waves
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 30 * 1024);    // 4 WG = 16 waves
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 44 * 1024);    // 3 WG = 12 waves
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 70 * 1024);    // 2 WG =  8 waves
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P, 140 * 1024);   // 1 WG =  4 waves
+    ab_add<F, G, true, true, 4, false, false, 0>(ab, name, P, 30 * 1024);
+    ab_add<F, 2 * G, true, true, 4, false, false, -1>(ab, name, P, 70 * 1024);
+    ab.run(15, 8);
+    free_pool(P);
+}
+
+template <class F, int G>
+static void ab_rows(const char* name, int qi)
+{
+    Pool P = make_pool(QTS[qi], 12);
+    AB ab;
+    ab_add<F, G, true, true, 4, false, false, -1>(ab, name, P);               // shipped: one group, 4 store rows
+    ab_add<F, G, true, true, 1, false, false, -1>(ab, name, P);
+    ab_add<F, G, false, true, 4, false, true, -1>(ab, name, P);               // direct (flat, row-serialised by the compiler)
+    ab_add<F, G / 4, true, true, 4, false, false, -1, 4>(ab, name, P);        // LDS, one row at a time, 4 rows per wave
+    ab_add<F, G / 4, false, true, 4, false, false, -1, 4>(ab, name, P);
+    ab_add<F, G / 4, true, true, 4, false, false, -1, 8>(ab, name, P);
+    ab_add<F, G / 4, true, true, 4, false, false, -1, 2>(ab, name, P);
+    ab_add<F, G / 2, true, true, 4, false, false, -1, 2>(ab, name, P);        // two rows at a time, twice
+    ab_add<F, G / 4, false, true, 4, false, true, -1, 4>(ab, name, P);        // direct, explicit row serialisation
+    ab.run(15, 8);
+    free_pool(P);
+}
+
+static void ab_all()
+{
+    ab_rows<ggq::FmtQ4_K, 8>("Q4_K", 7);
+    ab_rows<ggq::FmtQ2_K, 8>("Q2_K", 5);
+    ab_rows<ggq::FmtQ6_K, 8>("Q6_K", 9);
+    ab_rows<ggq::FmtQ4_0, 64>("Q4_0", 0);
+    ab_rows<ggq::FmtQ5_0, 64>("Q5_0", 2);
 }
 
 // every format through the shipped library (plan API), as bench.py drives it
@@ -405,5 +626,8 @@ int main(int argc, char** argv)
     if (what == "formats" || what == "all") formats();
     if (what == "variants" || what == "all") variants();
     if (what == "pmc") pmc_sequence();
+    if (what == "skel") skeletons();
+    if (what == "pmc2") pmc2_sequence();
+    if (what == "ab") ab_all();
     return rc ? 1 : 0;
 }
