@@ -5,9 +5,12 @@
 
 A "step" is ONE pass of the hot path over the whole synthetic pool: a DequantPlan launch
 (include/ggq.h ggq_plan_launch) over `pairs` x (3072x3072 + 3072x12288) FLUX.1-dev-shaped
-linears of one quant type -- 0.97 GB of traffic per step for Q4_K, far beyond the 256 MiB
-Infinity Cache, every tensor with its own packed and output buffers.  Packed inputs are resident
-in HBM before the timed region starts.
+linears of one quant type, every tensor with its own packed and output buffers.  The default pool
+(64 pairs = 3.0 G elements) is sized so that the PACKED bytes alone (0.99 GB for Q2_K ... 3.2 GB
+for Q8_0; 1.7 GB for Q4_K) are several times the 256 MiB Infinity Cache: with a pool whose packed
+bytes fit in it (8 pairs of Q4_K = 212 MB) the cache keeps the inputs resident across steps and the
+same kernel reads 5-15 % "faster" than HBM can deliver (profiles/r01_microbench_j_bigpool.txt).
+Packed inputs are resident in HBM before the timed region starts; 7.7 GB of traffic per Q4_K step.
 
 Headline workload: Q4_K (the north-star target format, BASELINE.json configs[2]); configs[1]
 (Q4_0) and every other format are measured the same way and reported under "per_qtype".
@@ -149,7 +152,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--qtype", default="Q4_K", help="headline quant type (default: the north-star target Q4_K)")
-    ap.add_argument("--pairs", type=int, default=8, help="(3072x3072 + 3072x12288) pairs in the per-GPU pool")
+    ap.add_argument("--pairs", type=int, default=64, help="(3072x3072 + 3072x12288) pairs in the per-GPU pool")
     ap.add_argument("--no-per-qtype", action="store_true", help="skip the per-format table")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -217,7 +220,7 @@ def main():
 
     per_qtype = {}
     if not args.no_per_qtype and rank == 0 and world == 1:
-        steps_q = max(10, args.steps // 2)
+        steps_q = max(10, args.steps // 3)
         for q in qt.HIP_QTYPES:
             if q == head_q:
                 per_qtype[q.name] = {"GB/s": result["roofline"]["achieved"], "pct_hbm_peak": round(100 * result["roofline"]["frac"], 2)}

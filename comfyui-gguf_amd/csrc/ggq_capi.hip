@@ -11,22 +11,23 @@ namespace {
 
 using namespace ggq;
 
-// Launch geometry, chosen by interleaved A/B runs on MI355X (DESIGN.md section 4 "Tuning",
-// profiles/r01_microbench_*): one group of 2048 output elements per wavefront, non-temporal stores.
-//   * default: the group's packed bytes are staged through a wave-private LDS slice with wide
-//     non-temporal loads; one wave per workgroup (1-3 % better than 4 for the 4-bit formats);
-//   * DIRECT for the formats where it measured faster -- Q2_K and Q3_K (smallest blocks: 7.1-7.2 TB/s
-//     vs 6.0 staged) and Q5_0 (2-byte-aligned blocks whose staged LDS reads replay): every lane reads
-//     its few bytes straight from global memory through the vector L1, row by row.
+// Launch geometry, chosen by interleaved A/B runs on MI355X over pools whose PACKED bytes alone are
+// 4-12x the 256 MiB Infinity Cache (DESIGN.md section 4 "Tuning", profiles/r01_microbench_j_*):
+//   * one group of 2048 output elements per wavefront, staged through a wave-private LDS slice;
+//   * one wave per workgroup (0.5-4 % better than four, never worse);
+//   * non-temporal stores (+3-4 %); non-temporal loads are a wash for the 4/5/8-bit formats and cost
+//     2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
+// The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
+// artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
 template <class F> struct Tune {
     static constexpr int G = (F::BS == 256) ? 8 : 64;
     static constexpr bool DIRECT = false;
     static constexpr bool NTL = true, NTS = true;
     static constexpr int WAVES = 1;
 };
-template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
-template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
-template <> struct Tune<FmtQ5_0> { static constexpr int G = 64; static constexpr bool DIRECT = true, NTL = false, NTS = true; static constexpr int WAVES = 4; };
+template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
+template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
+template <> struct Tune<FmtQ6_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
 
 thread_local int t_last_hip = 0;
 constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;

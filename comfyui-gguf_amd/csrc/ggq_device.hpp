@@ -60,18 +60,44 @@ GGQ_DEV uint32_t lds_u8(const uint8_t* p) { return *p; }
 GGQ_DEV uint32_t lds_u16(const uint8_t* p) { return *reinterpret_cast<const uint16_t*>(p); }
 GGQ_DEV _Float16 lds_h(const uint8_t* p) { return __builtin_bit_cast(_Float16, *reinterpret_cast<const uint16_t*>(p)); }
 
-template <int ALIGN>
+// A block whose size is 2 (mod 4) puts every other block at a 2-byte-aligned address.  hipcc would
+// merge four u16 reads there into ONE misaligned ds_read_b64, which the LDS replays (measured:
+// SQ_LDS_UNALIGNED_STALL 3.7e8-7.3e8 quad-cycles per launch on Q4_0 / Q8_0 / Q6_K / Q5_0, 0 on the
+// aligned formats).  So, when the bytes are in LDS: read the enclosing ALIGNED dwords -- volatile
+// on an explicit LDS-address-space pointer, so that they stay separate ds_read_b32 -- and
+// funnel-shift them into place with v_alignbyte_b32.  (LDS = false: the same code pointed at
+// global memory, where a misaligned load costs nothing; used only by the DIRECT engine.)
+typedef const volatile __attribute__((address_space(3))) uint32_t* lds_dword_ptr;
+GGQ_DEV uint32_t lds_dword(const uint8_t* p4) { return *(lds_dword_ptr)(p4); }
+
+template <int ALIGN, bool LDS>
 GGQ_DEV uint32_t lds_ld4(const uint8_t* p)
 {
-    if constexpr (ALIGN >= 4) return *reinterpret_cast<const uint32_t*>(p);
-    else return lds_u16(p) | (lds_u16(p + 2) << 16);
+    if constexpr (ALIGN >= 4) {
+        return *reinterpret_cast<const uint32_t*>(p);
+    } else if constexpr (!LDS) {
+        return lds_u16(p) | (lds_u16(p + 2) << 16);
+    } else {
+        const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 2u;
+        const uint8_t* q = p - sh;
+        const uint32_t d0 = lds_dword(q), d1 = lds_dword(q + 4);
+        return __builtin_amdgcn_alignbyte(d1, d0, sh);
+    }
 }
 
-template <int ALIGN>
+template <int ALIGN, bool LDS>
 GGQ_DEV u32x2 lds_ld8(const uint8_t* p)
 {
-    if constexpr (ALIGN >= 8) return *reinterpret_cast<const u32x2*>(p);
-    else return u32x2{lds_ld4<ALIGN>(p), lds_ld4<ALIGN>(p + 4)};
+    if constexpr (ALIGN >= 8) {
+        return *reinterpret_cast<const u32x2*>(p);
+    } else if constexpr (ALIGN >= 4 || !LDS) {
+        return u32x2{lds_ld4<ALIGN, LDS>(p), lds_ld4<ALIGN, LDS>(p + 4)};
+    } else {
+        const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 2u;
+        const uint8_t* q = p - sh;
+        const uint32_t d0 = lds_dword(q), d1 = lds_dword(q + 4), d2 = lds_dword(q + 8);
+        return u32x2{__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh)};
+    }
 }
 
 // 4 byte-fields t (one per byte, value < 1024 after OR-ing `extra`) -> two h2 of (field - bias)
@@ -95,10 +121,11 @@ GGQ_DEV uint32_t bits4_to_bytes(uint32_t x) { return ((x & 15u) * 0x00204081u) &
 // dequant.py:65-69    [d f16][qs i8 x32]            out = rn(d * qs)
 struct FmtQ8_0 {
     static constexpr int ID = 8, BS = 32, TS = 34, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const h2 d = splat(lds_h(b));
-        const u32x2 w = lds_ld8<2>(b + 2 + 8 * j);
+        const u32x2 w = lds_ld8<2, LDS>(b + 2 + 8 * j);
         // int8 x -> (x ^ 0x80) = x + 128 unsigned; 1024 + 128 + x - 1152 = x
         const H2x2 q0 = fields_h2(w.x ^ 0x80808080u, 128.0f), q1 = fields_h2(w.y ^ 0x80808080u, 128.0f);
         return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
@@ -107,10 +134,10 @@ struct FmtQ8_0 {
 
 // the 8 nibbles feeding chunk j of a 32-element legacy block whose 16 quant bytes start at qs:
 // j = 0,1 -> low nibbles of qs[8j..], j = 2,3 -> high nibbles of qs[8(j-2)..]    (dequant.py:121-122)
-template <int ALIGN>
+template <int ALIGN, bool LDS>
 GGQ_DEV u32x2 legacy_nibbles(const uint8_t* qs, int j)
 {
-    const u32x2 w = lds_ld8<ALIGN>(qs + 8 * (j & 1));
+    const u32x2 w = lds_ld8<ALIGN, LDS>(qs + 8 * (j & 1));
     const int sh = (j >> 1) * 4;
     return u32x2{(w.x >> sh) & 0x0F0F0F0Fu, (w.y >> sh) & 0x0F0F0F0Fu};
 }
@@ -118,10 +145,11 @@ GGQ_DEV u32x2 legacy_nibbles(const uint8_t* qs, int j)
 // dequant.py:115-123  [d][qs u8 x16]                out = rn(d * (q - 8))
 struct FmtQ4_0 {
     static constexpr int ID = 2, BS = 32, TS = 18, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const h2 d = splat(lds_h(b));
-        const u32x2 t = legacy_nibbles<2>(b + 2, j);
+        const u32x2 t = legacy_nibbles<2, LDS>(b + 2, j);
         const H2x2 q0 = fields_h2(t.x, 8.0f), q1 = fields_h2(t.y, 8.0f);
         return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
     }
@@ -130,11 +158,12 @@ struct FmtQ4_0 {
 // dequant.py:103-113  [d][m][qs x16]                out = rn(rn(d * q) + m)
 struct FmtQ4_1 {
     static constexpr int ID = 3, BS = 32, TS = 20, LDS_ALIGN = 4;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
-        const h2 dm = as_h2(lds_ld4<4>(b));
+        const h2 dm = as_h2(lds_ld4<4, LDS>(b));
         const h2 d = bcast_lo(dm), m = bcast_hi(dm);
-        const u32x2 t = legacy_nibbles<4>(b + 4, j);
+        const u32x2 t = legacy_nibbles<4, LDS>(b + 4, j);
         const H2x2 q0 = fields_h2(t.x, 0.0f), q1 = fields_h2(t.y, 0.0f);
         return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
     }
@@ -143,11 +172,12 @@ struct FmtQ4_1 {
 // dequant.py:87-101   [d][qh u32][qs x16]           q = nib | bit(qh, e) << 4;  out = rn(d * (q - 16))
 struct FmtQ5_0 {
     static constexpr int ID = 6, BS = 32, TS = 22, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const h2 d = splat(lds_h(b));
-        const uint32_t qh = lds_ld4<2>(b + 2) >> (8 * j);
-        const u32x2 t = legacy_nibbles<2>(b + 6, j);
+        const uint32_t qh = lds_ld4<2, LDS>(b + 2) >> (8 * j);
+        const u32x2 t = legacy_nibbles<2, LDS>(b + 6, j);
         const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 16.0f);
         const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 16.0f);
         return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
@@ -157,12 +187,13 @@ struct FmtQ5_0 {
 // dequant.py:71-85    [d][m][qh u32][qs x16]        out = rn(rn(d * q) + m)
 struct FmtQ5_1 {
     static constexpr int ID = 7, BS = 32, TS = 24, LDS_ALIGN = 8;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
-        const h2 dm = as_h2(lds_ld4<4>(b));
+        const h2 dm = as_h2(lds_ld4<4, LDS>(b));
         const h2 d = bcast_lo(dm), m = bcast_hi(dm);
-        const uint32_t qh = lds_ld4<4>(b + 4) >> (8 * j);
-        const u32x2 t = legacy_nibbles<8>(b + 8, j);
+        const uint32_t qh = lds_ld4<4, LDS>(b + 4) >> (8 * j);
+        const u32x2 t = legacy_nibbles<8, LDS>(b + 8, j);
         const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 0.0f);
         const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 0.0f);
         return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
@@ -183,10 +214,11 @@ GGQ_DEV uint32_t kvalues4(uint32_t t /* 4 nibble-bytes */)
 // dequant.py:243-256  [d][qs x16]                   out = rn(d * KVALUES[q])
 struct FmtIQ4_NL {
     static constexpr int ID = 20, BS = 32, TS = 18, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const h2 d = splat(lds_h(b));
-        const u32x2 t = legacy_nibbles<2>(b + 2, j);
+        const u32x2 t = legacy_nibbles<2, LDS>(b + 2, j);
         const H2x2 q0 = fields_h2(kvalues4(t.x) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t.y) ^ 0x80808080u, 128.0f);
         return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
     }
@@ -209,12 +241,13 @@ GGQ_DEV h2 k_dl_ml(u32x4 hdr, int sb)
 // dequant.py:180-195  [d][dmin][scales 12][qs 128]  out = rn(rn(rn(d*sc) * q) - rn(dmin*mn))
 struct FmtQ4_K {
     static constexpr int ID = 12, BS = 256, TS = 144, LDS_ALIGN = 16;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int sb = j >> 2;
         const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);                // (d*sc, dmin*mn)
         const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
-        const u32x2 w = lds_ld8<8>(b + 16 + 32 * (sb >> 1) + 8 * (j & 3));
+        const u32x2 w = lds_ld8<8, LDS>(b + 16 + 32 * (sb >> 1) + 8 * (j & 3));
         const int sh = (sb & 1) * 4;
         const H2x2 q0 = fields_h2((w.x >> sh) & 0x0F0F0F0Fu, 0.0f), q1 = fields_h2((w.y >> sh) & 0x0F0F0F0Fu, 0.0f);
         return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
@@ -224,13 +257,14 @@ struct FmtQ4_K {
 // dequant.py:159-178  [d][dmin][scales 12][qh 32][qs 128]   q = nib | bit(qh[l], sb) << 4
 struct FmtQ5_K {
     static constexpr int ID = 13, BS = 256, TS = 176, LDS_ALIGN = 16;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int sb = j >> 2;
         const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);
         const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
-        const u32x2 h = lds_ld8<8>(b + 16 + 8 * (j & 3));
-        const u32x2 w = lds_ld8<8>(b + 48 + 32 * (sb >> 1) + 8 * (j & 3));
+        const u32x2 h = lds_ld8<8, LDS>(b + 16 + 8 * (j & 3));
+        const u32x2 w = lds_ld8<8, LDS>(b + 48 + 32 * (sb >> 1) + 8 * (j & 3));
         const int sh = (sb & 1) * 4;
         const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> sb) & 0x01010101u) << 4);
         const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> sb) & 0x01010101u) << 4);
@@ -242,13 +276,14 @@ struct FmtQ5_K {
 // dequant.py:141-157  [ql 128][qh 64][scales i8 x16][d]     out = rn(rn(d*scale) * (q - 32))
 struct FmtQ6_K {
     static constexpr int ID = 14, BS = 256, TS = 210, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
         const _Float16 sc = (_Float16)(int16_t)(int8_t)lds_u8(b + 192 + (j >> 1));
         const h2 dl = splat(lds_h(b + 208) * sc);
-        const u32x2 w = lds_ld8<2>(b + 64 * half + 32 * (k & 1) + 8 * c4);
-        const u32x2 h = lds_ld8<2>(b + 128 + 32 * half + 8 * c4);
+        const u32x2 w = lds_ld8<2, LDS>(b + 64 * half + 32 * (k & 1) + 8 * c4);
+        const u32x2 h = lds_ld8<2, LDS>(b + 128 + 32 * half + 8 * c4);
         const int sh = (k >> 1) * 4;
         const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> (2 * k)) & 0x03030303u) << 4);
         const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> (2 * k)) & 0x03030303u) << 4);
@@ -260,13 +295,14 @@ struct FmtQ6_K {
 // dequant.py:221-238  [scales 16][qs 64][d][dmin]   out = rn(rn(rn(d*(s&15)) * q) - rn(dmin*(s>>4)))
 struct FmtQ2_K {
     static constexpr int ID = 10, BS = 256, TS = 84, LDS_ALIGN = 4;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
         const uint32_t s = lds_u8(b + (j >> 1));
-        const h2 dlml = as_h2(lds_ld4<4>(b + 80)) * ints_h2((s & 15u) | ((s >> 4) << 16), 0.0f);
+        const h2 dlml = as_h2(lds_ld4<4, LDS>(b + 80)) * ints_h2((s & 15u) | ((s >> 4) << 16), 0.0f);
         const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
-        const u32x2 w = lds_ld8<4>(b + 16 + 32 * half + 8 * c4);
+        const u32x2 w = lds_ld8<4, LDS>(b + 16 + 32 * half + 8 * c4);
         const H2x2 q0 = fields_h2((w.x >> (2 * k)) & 0x03030303u, 0.0f), q1 = fields_h2((w.y >> (2 * k)) & 0x03030303u, 0.0f);
         return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
     }
@@ -275,6 +311,7 @@ struct FmtQ2_K {
 // dequant.py:197-219  [hmask 32][qs 64][scales 12][d]   out = rn(rn(d*(scale-32)) * (ql - (hb ? 0 : 4)))
 struct FmtQ3_K {
     static constexpr int ID = 11, BS = 256, TS = 110, LDS_ALIGN = 2;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3, jj = j >> 1;
@@ -282,8 +319,8 @@ struct FmtQ3_K {
         const uint32_t hi = (lds_u8(b + 104 + (jj & 3)) >> (2 * (jj >> 2))) & 3u;
         const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
         const h2 dl = splat(lds_h(b + 108) * sc);
-        const u32x2 w = lds_ld8<2>(b + 32 + 32 * half + 8 * c4);
-        const u32x2 hm = lds_ld8<2>(b + 8 * c4);
+        const u32x2 w = lds_ld8<2, LDS>(b + 32 + 32 * half + 8 * c4);
+        const u32x2 hm = lds_ld8<2, LDS>(b + 8 * c4);
         const int hs = j >> 2;
         // q = ql - 4*(1-hb) = (ql | hb << 2) - 4
         const uint32_t t0 = ((w.x >> (2 * k)) & 0x03030303u) | (((hm.x >> hs) & 0x01010101u) << 2);
@@ -296,6 +333,7 @@ struct FmtQ3_K {
 // dequant.py:258-285  [d][scales_h u16][scales_l 4][qs 128]   out = rn(rn(d*(scale-32)) * KVALUES[q])
 struct FmtIQ4_XS {
     static constexpr int ID = 23, BS = 256, TS = 136, LDS_ALIGN = 8;
+    template <bool LDS>
     GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
     {
         const int g = j >> 2, c4 = j & 3;
@@ -303,7 +341,7 @@ struct FmtIQ4_XS {
         const uint32_t hi = (lds_u16(b + 2) >> (2 * g)) & 3u;
         const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
         const h2 dl = splat(lds_h(b) * sc);
-        const u32x2 w = lds_ld8<8>(b + 8 + 16 * g + 8 * (c4 & 1));
+        const u32x2 w = lds_ld8<8, LDS>(b + 8 + 16 * g + 8 * (c4 & 1));
         const int sh = (c4 >> 1) * 4;
         const uint32_t t0 = (w.x >> sh) & 0x0F0F0F0Fu, t1 = (w.y >> sh) & 0x0F0F0F0Fu;
         const H2x2 q0 = fields_h2(kvalues4(t0) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t1) ^ 0x80808080u, 128.0f);
@@ -320,18 +358,25 @@ enum : int { OUT_F16 = 0, OUT_BF16 = 1, OUT_F32 = 2 };
 template <int OUT> struct OutBytes { static constexpr int V = 2; };
 template <> struct OutBytes<OUT_F32> { static constexpr int V = 4; };
 
+// Device-memory pointers are typed as such (address space 1): a pointer that comes out of a
+// descriptor table has no address space the compiler could infer, and every access through it
+// would become a flat_* instruction -- which also occupies lgkmcnt, the counter the LDS reads wait on.
+#define GGQ_GLOBAL __attribute__((address_space(1)))
+typedef GGQ_GLOBAL const uint8_t* gcptr;
+typedef GGQ_GLOBAL uint8_t* gptr;
+
 template <bool NT, class T>
-GGQ_DEV void gstore(T* p, T v)
+GGQ_DEV void gstore(gptr p, T v)
 {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    if constexpr (NT) __builtin_nontemporal_store(v, (GGQ_GLOBAL T*)p);
+    else *(GGQ_GLOBAL T*)p = v;
 }
 
 template <bool NT>
-GGQ_DEV u32x4 gload16(const uint8_t* p)
+GGQ_DEV u32x4 gload16(gcptr p)
 {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    else return *reinterpret_cast<const u32x4*>(p);
+    if constexpr (NT) return __builtin_nontemporal_load((GGQ_GLOBAL const u32x4*)p);
+    else return *(GGQ_GLOBAL const u32x4*)p;
 }
 
 GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh)
@@ -347,18 +392,17 @@ GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh)
 }
 
 template <int OUT, bool NT>
-GGQ_DEV void store_chunk(uint8_t* out, uint64_t elem, u32x4 v)
+GGQ_DEV void store_chunk(gptr out, uint64_t elem, u32x4 v)
 {
     if constexpr (OUT == OUT_F16) {
-        gstore<NT>(reinterpret_cast<u32x4*>(out + elem * 2), v);
+        gstore<NT>(out + elem * 2, v);
     } else if constexpr (OUT == OUT_BF16) {
         const u32x4 r{h2_to_bf16x2(v.x), h2_to_bf16x2(v.y), h2_to_bf16x2(v.z), h2_to_bf16x2(v.w)};
-        gstore<NT>(reinterpret_cast<u32x4*>(out + elem * 2), r);
+        gstore<NT>(out + elem * 2, r);
     } else {
         const h2 a = as_h2(v.x), b = as_h2(v.y), c = as_h2(v.z), d = as_h2(v.w);
-        f32x4* p = reinterpret_cast<f32x4*>(out + elem * 4);
-        gstore<NT>(p, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
-        gstore<NT>(p + 1, f32x4{(float)c.x, (float)c.y, (float)d.x, (float)d.y});
+        gstore<NT>(out + elem * 4, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
+        gstore<NT>(out + elem * 4 + 16, f32x4{(float)c.x, (float)c.y, (float)d.x, (float)d.y});
     }
 }
 
@@ -374,8 +418,8 @@ struct Desc {
 };
 
 struct Work {
-    const uint8_t* packed;
-    uint8_t* out;
+    gcptr packed;
+    gptr out;
     uint64_t n_blocks;
     uint64_t lg;   // group index inside the tensor
 };
@@ -431,7 +475,7 @@ struct Engine {
     {
         const uint64_t off = w.lg * (uint64_t)GROUP_BYTES;
         const uint32_t a = ALIGNED ? 0u : ((uint32_t)off & 15u);            // wave-uniform
-        const uint8_t* base = w.packed + off - a;
+        const gcptr base = w.packed + off - a;
         uint32_t valid = a + (uint32_t)GROUP_BYTES;
         if constexpr (!FULL) {
             const uint64_t left = w.n_blocks * (uint64_t)TS - off;           // > 0 by construction
@@ -459,7 +503,7 @@ struct Engine {
             const int bl = chunk / CPB, j = chunk % CPB;
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
-                const u32x4 v = F::chunk(slice + a + bl * TS, j);
+                const u32x4 v = F::template chunk<true>(slice + a + bl * TS, j);
                 store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
             }
             if (s + 1 < NCH) store_throttle<THR>();
@@ -479,7 +523,7 @@ struct Engine {
             const int bl = chunk / CPB, j = chunk % CPB;
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
-                const u32x4 v = F::chunk(w.packed + gb * (uint64_t)TS, j);
+                const u32x4 v = F::template chunk<false>((const uint8_t*)(w.packed + gb * (uint64_t)TS), j);
                 store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
             }
         }
@@ -527,7 +571,7 @@ struct Engine {
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
 __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) { return Work{d.packed, d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group
@@ -541,7 +585,7 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
             if (table[mid].first_group <= g) lo = mid; else hi = mid;
         }
         const Desc d = table[lo];
-        return Work{d.packed, d.out, d.n_blocks, g - d.first_group};
+        return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};
     });
 }
 

@@ -13,9 +13,10 @@ FLUX_B = (3072, 3072)       # BASELINE shape B
 FLUX_C = (3072, 12288)      # BASELINE shape C
 
 
-def flux_linear_pool(qtype, pairs=8):
+def flux_linear_pool(qtype, pairs=64):
     """configs[1]/[2]: ``pairs`` x (3072x3072 + 3072x12288) FLUX.1-dev-shaped linears of one format.
-    8 pairs = 0.38 G elements: 0.97 GB of traffic for a 4.5-bit format, far beyond the 256 MiB MALL."""
+    64 pairs = 3.0 G elements: even the smallest format's PACKED bytes (Q2_K, 0.99 GB) are ~4x the
+    256 MiB Infinity Cache, so neither the inputs nor the outputs of one step survive to the next."""
     out = []
     for i in range(pairs):
         out.append((f"pool.{i}.proj", Q(int(qtype)), FLUX_B))
