@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--qtype", default="Q4_K", help="headline quant type (default: the north-star target Q4_K)")
     ap.add_argument("--pairs", type=int, default=64, help="(3072x3072 + 3072x12288) pairs in the per-GPU pool")
     ap.add_argument("--no-per-qtype", action="store_true", help="skip the per-format table")
+    ap.add_argument("--no-per-mode", action="store_true", help="skip the (dequant_dtype, dtype) table of the headline format")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -233,6 +234,26 @@ def main():
             del p
             torch.cuda.empty_cache()
         result["per_qtype"] = per_qtype
+
+    if not args.no_per_mode and rank == 0 and world == 1:
+        # the other (dequant_dtype -> dtype) combinations dequantize_tensor can be asked for (dequant.py:15-23,
+        # nodes.py:186), same packed pool, fresh outputs; bytes = packed + dense bytes of THAT output dtype
+        per_mode = {}
+        steps_m = max(10, args.steps // 3)
+        names = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}
+        shapes = [tuple(o.shape) for o in plan_head.outputs]
+        for cd in (torch.float16, torch.bfloat16, torch.float32):
+            for od in (torch.float16, torch.bfloat16, torch.float32):
+                if cd == torch.float16 and od == torch.float16:
+                    continue
+                p = pkg.grouped.DequantPlan([(d, head_q, sh) for d, sh in zip(plan_head._keep, shapes)], out_dtype=od, dequant_dtype=cd)
+                ms, _ = timed_steps(p, steps_m, 3, device, lambda: torch.cuda.synchronize(device))
+                gbs = p.bytes / (ms / steps_m * 1e-3) / 1e9
+                per_mode[f"{names[cd]}->{names[od]}"] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2)}
+                p.close()
+                del p
+                torch.cuda.empty_cache()
+        result["per_mode"] = per_mode
 
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:

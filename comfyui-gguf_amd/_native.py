@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(ROOT, "include", "ggq.h")]
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -29,14 +29,16 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 _FMA_RE = re.compile(r"\b(v_(?:pk_)?(?:fma|fmac)_\w+|v_mad_(?:f16|f32|legacy_f\w+|mix\w*|mixlo\w*|mixhi\w*)\w*)")
 
 GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM = range(6)
-OUT_F16, OUT_BF16, OUT_F32 = 0, 1, 2
+F16, BF16, F32 = 0, 1, 2          # ggq_dtype: compute and out dtypes
+OUT_F16, OUT_BF16, OUT_F32 = F16, BF16, F32
 
 # every symbol include/ggq.h declares: name -> (restype, argtypes)
 _u64, _u32, _int, _vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p
 
 
 class ggq_desc(ctypes.Structure):
-    _fields_ = [("qtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("packed", _vp), ("out", _vp), ("n_blocks", _u64)]
+    _fields_ = [("qtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("packed", _vp), ("out", _vp), ("n_blocks", _u64),
+                ("compute_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 SYMBOLS = {
@@ -46,7 +48,7 @@ SYMBOLS = {
     "ggq_strerror": (ctypes.c_char_p, [_int]),
     "ggq_last_hip_error": (_int, []),
     "ggq_abi_version": (_int, []),
-    "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _vp]),
+    "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
     "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),
     "ggq_plan_launch": (_int, [_vp, _vp]),

@@ -35,7 +35,7 @@ constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, hipStream_t);
 
-template <class F, int OUT>
+template <class F, int ARITH, int OUT>
 hipError_t run_one(const Desc& d, hipStream_t s)
 {
     using T = Tune<F>;
@@ -43,32 +43,33 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
     return hipGetLastError();
 }
 
-template <class F, int OUT>
+template <class F, int ARITH, int OUT>
 hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t s)
 {
     using T = Tune<F>;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
     return hipGetLastError();
 }
 
 struct FormatEntry {
     int qtype, block_size, type_size, group;
-    one_fn one[3];
-    many_fn many[3];
+    one_fn one[3][3];      // [compute dtype][out dtype]
+    many_fn many[3][3];
 };
 
+#define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
 #define GGQ_FORMAT(F)                                                                          \
     FormatEntry {                                                                              \
         F::ID, F::BS, F::TS, Tune<F>::G,                                                       \
-        {run_one<F, OUT_F16>, run_one<F, OUT_BF16>, run_one<F, OUT_F32>},                      \
-        {run_many<F, OUT_F16>, run_many<F, OUT_BF16>, run_many<F, OUT_F32>}                    \
+        {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
+        {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)}    \
     }
 
 const FormatEntry FORMATS[] = {
@@ -93,10 +94,10 @@ int hip_fail(hipError_t e)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int check_tensor(const FormatEntry* f, const void* packed, const void* out, uint64_t n_blocks, int out_dtype)
+int check_tensor(const FormatEntry* f, const void* packed, const void* out, uint64_t n_blocks, int compute_dtype, int out_dtype)
 {
     if (!f) return GGQ_ERR_QTYPE;
-    if (out_dtype < 0 || out_dtype > 2) return GGQ_ERR_ARG;
+    if (out_dtype < 0 || out_dtype > 2 || compute_dtype < 0 || compute_dtype > 2) return GGQ_ERR_ARG;
     if (n_blocks == 0) return GGQ_OK;
     if (!packed || !out) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(out)) return GGQ_ERR_ALIGN;
@@ -105,7 +106,7 @@ int check_tensor(const FormatEntry* f, const void* packed, const void* out, uint
 
 struct Segment {
     const FormatEntry* fmt;
-    int out_dtype;
+    int compute_dtype, out_dtype;
     uint32_t first, count;     // slice of the device table
     uint64_t groups;
 };
@@ -121,7 +122,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 1; }
+int ggq_abi_version(void) { return 2; }
 
 int ggq_supported(int qtype) { return find_format(qtype) ? 1 : 0; }
 
@@ -152,19 +153,19 @@ const char* ggq_strerror(int status)
 
 int ggq_last_hip_error(void) { return t_last_hip; }
 
-int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int out_dtype, void* hip_stream)
+int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* hip_stream)
 {
     const FormatEntry* f = find_format(qtype);
-    const int rc = check_tensor(f, packed, out, n_blocks, out_dtype);
+    const int rc = check_tensor(f, packed, out, n_blocks, compute_dtype, out_dtype);
     if (rc != GGQ_OK || n_blocks == 0) return rc;
     const Desc d{static_cast<const uint8_t*>(packed), static_cast<uint8_t*>(out), n_blocks, 0};
-    const hipError_t e = f->one[out_dtype](d, static_cast<hipStream_t>(hip_stream));
+    const hipError_t e = f->one[compute_dtype][out_dtype](d, static_cast<hipStream_t>(hip_stream));
     return e == hipSuccess ? GGQ_OK : hip_fail(e);
 }
 
 int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream)
 {
-    return ggq_dequant(qtype, packed, n_blocks, out_f16, GGQ_OUT_F16, hip_stream);
+    return ggq_dequant(qtype, packed, n_blocks, out_f16, GGQ_F16, GGQ_F16, hip_stream);
 }
 
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
@@ -172,7 +173,7 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
     if (!plan_out || (n > 0 && !descs)) return GGQ_ERR_ARG;
     *plan_out = nullptr;
     for (uint32_t i = 0; i < n; i++) {
-        const int rc = check_tensor(find_format(descs[i].qtype), descs[i].packed, descs[i].out, descs[i].n_blocks, descs[i].out_dtype);
+        const int rc = check_tensor(find_format(descs[i].qtype), descs[i].packed, descs[i].out, descs[i].n_blocks, descs[i].compute_dtype, descs[i].out_dtype);
         if (rc != GGQ_OK) return rc;
     }
     ggq_plan* plan = new (std::nothrow) ggq_plan();
@@ -181,15 +182,16 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
     try {
         table.reserve(n);
         for (int fi = 0; fi < N_FORMATS; fi++) {
-            for (int od = 0; od < 3; od++) {
-                Segment seg{&FORMATS[fi], od, (uint32_t)table.size(), 0, 0};
+            for (int cd_od = 0; cd_od < 9; cd_od++) {
+                const int cd = cd_od / 3, od = cd_od % 3;
+                Segment seg{&FORMATS[fi], cd, od, (uint32_t)table.size(), 0, 0};
                 for (uint32_t i = 0; i < n; i++) {
                     const ggq_desc& d = descs[i];
-                    if (d.qtype != FORMATS[fi].qtype || d.out_dtype != od || d.n_blocks == 0) continue;
+                    if (d.qtype != FORMATS[fi].qtype || d.compute_dtype != cd || d.out_dtype != od || d.n_blocks == 0) continue;
                     table.push_back(Desc{static_cast<const uint8_t*>(d.packed), static_cast<uint8_t*>(d.out), d.n_blocks, seg.groups});
                     seg.groups += (d.n_blocks + FORMATS[fi].group - 1) / FORMATS[fi].group;
                     seg.count++;
-                    plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_OUT_F32 ? 4 : 2));
+                    plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_F32 ? 4 : 2));
                 }
                 if (seg.count) plan->segments.push_back(seg);
             }
@@ -216,7 +218,7 @@ int ggq_plan_launch(const ggq_plan* plan, void* hip_stream)
 {
     if (!plan) return GGQ_ERR_ARG;
     for (const Segment& seg : plan->segments) {
-        const hipError_t e = seg.fmt->many[seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, static_cast<hipStream_t>(hip_stream));
+        const hipError_t e = seg.fmt->many[seg.compute_dtype][seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, static_cast<hipStream_t>(hip_stream));
         if (e != hipSuccess) return hip_fail(e);
     }
     return GGQ_OK;

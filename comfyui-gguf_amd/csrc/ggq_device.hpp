@@ -111,24 +111,39 @@ GGQ_DEV H2x2 fields_h2(uint32_t t, float bias)
 GGQ_DEV uint32_t bits4_to_bytes(uint32_t x) { return ((x & 15u) * 0x00204081u) & 0x01010101u; }
 
 // ============================================================================ block formats
-// Each format: BS elements / TS bytes per block, and
-//   chunk(b, j): the 8 output elements [8j, 8j+8) of the block whose bytes start at LDS pointer b,
-//                as 4 x (2 x fp16) bit patterns.
+// Every ggml block format on this path has the same algebraic shape (dequant.py:65-285):
+//
+//     out[e] = (A * (field[e] - BIAS))  [+ m | - B]
+//
+// with A = d or rn(d * sc), B = rn(dmin * mn), `field` an unsigned byte-sized integer and d, m,
+// dmin fp16 values stored in the block.  A format therefore only has to DECODE: pick the 8 byte
+// fields of one chunk and the scale operands out of the packed bytes (pure integer work, shared by
+// all arithmetic modes); the arithmetic itself -- the reference's op sequence with its roundings,
+// in fp16 (default), bf16 or fp32 (the Advanced loader's dequant_dtype, nodes.py:186) -- is applied
+// by finish_*() below.
+//
+//   KIND   K_D     rn(d * (q - BIAS))                          Q8_0 Q4_0 Q5_0 IQ4_NL
+//          K_DM    rn(rn(d * q) + m)                           Q4_1 Q5_1
+//          K_SCMN  rn(rn(rn(d * sc) * q) - rn(dmin * mn))      Q2_K Q4_K Q5_K
+//          K_SC    rn(rn(d * sc) * (q - BIAS))                 Q3_K Q6_K IQ4_XS
+enum : int { K_D = 0, K_DM = 1, K_SCMN = 2, K_SC = 3 };
 
-#define GGQ_EMIT4(EXPR_A0, EXPR_B0, EXPR_A1, EXPR_B1) \
-    u32x4 { as_u32(EXPR_A0), as_u32(EXPR_B0), as_u32(EXPR_A1), as_u32(EXPR_B1) }
+// What one chunk (8 consecutive output elements [8j, 8j+8) of the block at `b`) decodes to.
+struct Fields {
+    uint32_t t0, t1;   // the 8 unsigned fields, one per byte: elements 0-3 in t0, 4-7 in t1
+    uint32_t dm;       // fp16 bits: low half = d, high half = m / dmin (K_DM, K_SCMN)
+    int32_t sc, mn;    // integer sub-block scale (K_SCMN, K_SC; signed for K_SC) and min (K_SCMN)
+};
 
 // dequant.py:65-69    [d f16][qs i8 x32]            out = rn(d * qs)
 struct FmtQ8_0 {
-    static constexpr int ID = 8, BS = 32, TS = 34, LDS_ALIGN = 2;
+    static constexpr int ID = 8, BS = 32, TS = 34, LDS_ALIGN = 2, KIND = K_D, BIAS = 128;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 d = splat(lds_h(b));
         const u32x2 w = lds_ld8<2, LDS>(b + 2 + 8 * j);
-        // int8 x -> (x ^ 0x80) = x + 128 unsigned; 1024 + 128 + x - 1152 = x
-        const H2x2 q0 = fields_h2(w.x ^ 0x80808080u, 128.0f), q1 = fields_h2(w.y ^ 0x80808080u, 128.0f);
-        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+        // int8 x -> (x ^ 0x80) = x + 128 unsigned
+        return Fields{w.x ^ 0x80808080u, w.y ^ 0x80808080u, lds_u16(b), 0, 0};
     }
 };
 
@@ -144,59 +159,47 @@ GGQ_DEV u32x2 legacy_nibbles(const uint8_t* qs, int j)
 
 // dequant.py:115-123  [d][qs u8 x16]                out = rn(d * (q - 8))
 struct FmtQ4_0 {
-    static constexpr int ID = 2, BS = 32, TS = 18, LDS_ALIGN = 2;
+    static constexpr int ID = 2, BS = 32, TS = 18, LDS_ALIGN = 2, KIND = K_D, BIAS = 8;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 d = splat(lds_h(b));
         const u32x2 t = legacy_nibbles<2, LDS>(b + 2, j);
-        const H2x2 q0 = fields_h2(t.x, 8.0f), q1 = fields_h2(t.y, 8.0f);
-        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+        return Fields{t.x, t.y, lds_u16(b), 0, 0};
     }
 };
 
 // dequant.py:103-113  [d][m][qs x16]                out = rn(rn(d * q) + m)
 struct FmtQ4_1 {
-    static constexpr int ID = 3, BS = 32, TS = 20, LDS_ALIGN = 4;
+    static constexpr int ID = 3, BS = 32, TS = 20, LDS_ALIGN = 4, KIND = K_DM, BIAS = 0;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 dm = as_h2(lds_ld4<4, LDS>(b));
-        const h2 d = bcast_lo(dm), m = bcast_hi(dm);
         const u32x2 t = legacy_nibbles<4, LDS>(b + 4, j);
-        const H2x2 q0 = fields_h2(t.x, 0.0f), q1 = fields_h2(t.y, 0.0f);
-        return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
+        return Fields{t.x, t.y, lds_ld4<4, LDS>(b), 0, 0};
     }
 };
 
 // dequant.py:87-101   [d][qh u32][qs x16]           q = nib | bit(qh, e) << 4;  out = rn(d * (q - 16))
 struct FmtQ5_0 {
-    static constexpr int ID = 6, BS = 32, TS = 22, LDS_ALIGN = 2;
+    static constexpr int ID = 6, BS = 32, TS = 22, LDS_ALIGN = 2, KIND = K_D, BIAS = 16;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 d = splat(lds_h(b));
         const uint32_t qh = lds_ld4<2, LDS>(b + 2) >> (8 * j);
         const u32x2 t = legacy_nibbles<2, LDS>(b + 6, j);
-        const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 16.0f);
-        const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 16.0f);
-        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+        return Fields{t.x | (bits4_to_bytes(qh) << 4), t.y | (bits4_to_bytes(qh >> 4) << 4), lds_u16(b), 0, 0};
     }
 };
 
 // dequant.py:71-85    [d][m][qh u32][qs x16]        out = rn(rn(d * q) + m)
 struct FmtQ5_1 {
-    static constexpr int ID = 7, BS = 32, TS = 24, LDS_ALIGN = 8;
+    static constexpr int ID = 7, BS = 32, TS = 24, LDS_ALIGN = 8, KIND = K_DM, BIAS = 0;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 dm = as_h2(lds_ld4<4, LDS>(b));
-        const h2 d = bcast_lo(dm), m = bcast_hi(dm);
         const uint32_t qh = lds_ld4<4, LDS>(b + 4) >> (8 * j);
         const u32x2 t = legacy_nibbles<8, LDS>(b + 8, j);
-        const H2x2 q0 = fields_h2(t.x | (bits4_to_bytes(qh) << 4), 0.0f);
-        const H2x2 q1 = fields_h2(t.y | (bits4_to_bytes(qh >> 4) << 4), 0.0f);
-        return GGQ_EMIT4(d * q0.a + m, d * q0.b + m, d * q1.a + m, d * q1.b + m);
+        return Fields{t.x | (bits4_to_bytes(qh) << 4), t.y | (bits4_to_bytes(qh >> 4) << 4), lds_ld4<4, LDS>(b), 0, 0};
     }
 };
 
@@ -213,141 +216,218 @@ GGQ_DEV uint32_t kvalues4(uint32_t t /* 4 nibble-bytes */)
 
 // dequant.py:243-256  [d][qs x16]                   out = rn(d * KVALUES[q])
 struct FmtIQ4_NL {
-    static constexpr int ID = 20, BS = 32, TS = 18, LDS_ALIGN = 2;
+    static constexpr int ID = 20, BS = 32, TS = 18, LDS_ALIGN = 2, KIND = K_D, BIAS = 128;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
-        const h2 d = splat(lds_h(b));
         const u32x2 t = legacy_nibbles<2, LDS>(b + 2, j);
-        const H2x2 q0 = fields_h2(kvalues4(t.x) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t.y) ^ 0x80808080u, 128.0f);
-        return GGQ_EMIT4(d * q0.a, d * q0.b, d * q1.a, d * q1.b);
+        return Fields{kvalues4(t.x) ^ 0x80808080u, kvalues4(t.y) ^ 0x80808080u, lds_u16(b), 0, 0};
     }
 };
 
 // ---- K-quants: 256-element super-blocks, 32 chunks each; chunk j covers elements 8j..8j+7.
 
 // dequant.py:129-139 get_scale_min.  hdr = the first 16 bytes of a Q4_K / Q5_K super-block
-// ([d][dmin][scales 12], one broadcast ds_read_b128); returns (d*sc, dmin*mn) for sub-block sb.
-GGQ_DEV h2 k_dl_ml(u32x4 hdr, int sb)
+// ([d][dmin][scales 12], one broadcast ds_read_b128); 6-bit (sc, mn) of sub-block sb, branch-free.
+GGQ_DEV void k_scale_min(u32x4 hdr, int sb, int32_t& sc, int32_t& mn)
 {
     const uint32_t sh = 8u * (uint32_t)(sb & 3);
     const uint32_t a = (hdr.y >> sh) & 0xFFu, bb = (hdr.z >> sh) & 0xFFu, c = (hdr.w >> sh) & 0xFFu;
     const uint32_t hi = 0u - (uint32_t)(sb >> 2);                    // all-ones for sub-blocks 4..7
-    const uint32_t sc = ((a & 63u) & ~hi) | (((c & 15u) | ((a >> 2) & 0x30u)) & hi);
-    const uint32_t mn = ((bb & 63u) & ~hi) | (((c >> 4) | ((bb >> 2) & 0x30u)) & hi);
-    return as_h2(hdr.x) * ints_h2(sc | (mn << 16), 0.0f);
+    sc = (int32_t)(((a & 63u) & ~hi) | (((c & 15u) | ((a >> 2) & 0x30u)) & hi));
+    mn = (int32_t)(((bb & 63u) & ~hi) | (((c >> 4) | ((bb >> 2) & 0x30u)) & hi));
 }
 
 // dequant.py:180-195  [d][dmin][scales 12][qs 128]  out = rn(rn(rn(d*sc) * q) - rn(dmin*mn))
 struct FmtQ4_K {
-    static constexpr int ID = 12, BS = 256, TS = 144, LDS_ALIGN = 16;
+    static constexpr int ID = 12, BS = 256, TS = 144, LDS_ALIGN = 16, KIND = K_SCMN, BIAS = 0;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int sb = j >> 2;
-        const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);                // (d*sc, dmin*mn)
-        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        const u32x4 hdr = *reinterpret_cast<const u32x4*>(b);
+        Fields f;
+        k_scale_min(hdr, sb, f.sc, f.mn);
         const u32x2 w = lds_ld8<8, LDS>(b + 16 + 32 * (sb >> 1) + 8 * (j & 3));
         const int sh = (sb & 1) * 4;
-        const H2x2 q0 = fields_h2((w.x >> sh) & 0x0F0F0F0Fu, 0.0f), q1 = fields_h2((w.y >> sh) & 0x0F0F0F0Fu, 0.0f);
-        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+        f.t0 = (w.x >> sh) & 0x0F0F0F0Fu;
+        f.t1 = (w.y >> sh) & 0x0F0F0F0Fu;
+        f.dm = hdr.x;
+        return f;
     }
 };
 
 // dequant.py:159-178  [d][dmin][scales 12][qh 32][qs 128]   q = nib | bit(qh[l], sb) << 4
 struct FmtQ5_K {
-    static constexpr int ID = 13, BS = 256, TS = 176, LDS_ALIGN = 16;
+    static constexpr int ID = 13, BS = 256, TS = 176, LDS_ALIGN = 16, KIND = K_SCMN, BIAS = 0;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int sb = j >> 2;
-        const h2 dlml = k_dl_ml(*reinterpret_cast<const u32x4*>(b), sb);
-        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        const u32x4 hdr = *reinterpret_cast<const u32x4*>(b);
+        Fields f;
+        k_scale_min(hdr, sb, f.sc, f.mn);
         const u32x2 h = lds_ld8<8, LDS>(b + 16 + 8 * (j & 3));
         const u32x2 w = lds_ld8<8, LDS>(b + 48 + 32 * (sb >> 1) + 8 * (j & 3));
         const int sh = (sb & 1) * 4;
-        const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> sb) & 0x01010101u) << 4);
-        const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> sb) & 0x01010101u) << 4);
-        const H2x2 q0 = fields_h2(t0, 0.0f), q1 = fields_h2(t1, 0.0f);
-        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+        f.t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> sb) & 0x01010101u) << 4);
+        f.t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> sb) & 0x01010101u) << 4);
+        f.dm = hdr.x;
+        return f;
     }
 };
 
 // dequant.py:141-157  [ql 128][qh 64][scales i8 x16][d]     out = rn(rn(d*scale) * (q - 32))
 struct FmtQ6_K {
-    static constexpr int ID = 14, BS = 256, TS = 210, LDS_ALIGN = 2;
+    static constexpr int ID = 14, BS = 256, TS = 210, LDS_ALIGN = 2, KIND = K_SC, BIAS = 32;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
-        const _Float16 sc = (_Float16)(int16_t)(int8_t)lds_u8(b + 192 + (j >> 1));
-        const h2 dl = splat(lds_h(b + 208) * sc);
+        Fields f;
+        f.sc = (int32_t)(int8_t)lds_u8(b + 192 + (j >> 1));
+        f.mn = 0;
+        f.dm = lds_u16(b + 208);
         const u32x2 w = lds_ld8<2, LDS>(b + 64 * half + 32 * (k & 1) + 8 * c4);
         const u32x2 h = lds_ld8<2, LDS>(b + 128 + 32 * half + 8 * c4);
         const int sh = (k >> 1) * 4;
-        const uint32_t t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> (2 * k)) & 0x03030303u) << 4);
-        const uint32_t t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> (2 * k)) & 0x03030303u) << 4);
-        const H2x2 q0 = fields_h2(t0, 32.0f), q1 = fields_h2(t1, 32.0f);
-        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+        f.t0 = ((w.x >> sh) & 0x0F0F0F0Fu) | (((h.x >> (2 * k)) & 0x03030303u) << 4);
+        f.t1 = ((w.y >> sh) & 0x0F0F0F0Fu) | (((h.y >> (2 * k)) & 0x03030303u) << 4);
+        return f;
     }
 };
 
 // dequant.py:221-238  [scales 16][qs 64][d][dmin]   out = rn(rn(rn(d*(s&15)) * q) - rn(dmin*(s>>4)))
 struct FmtQ2_K {
-    static constexpr int ID = 10, BS = 256, TS = 84, LDS_ALIGN = 4;
+    static constexpr int ID = 10, BS = 256, TS = 84, LDS_ALIGN = 4, KIND = K_SCMN, BIAS = 0;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3;
         const uint32_t s = lds_u8(b + (j >> 1));
-        const h2 dlml = as_h2(lds_ld4<4, LDS>(b + 80)) * ints_h2((s & 15u) | ((s >> 4) << 16), 0.0f);
-        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
         const u32x2 w = lds_ld8<4, LDS>(b + 16 + 32 * half + 8 * c4);
-        const H2x2 q0 = fields_h2((w.x >> (2 * k)) & 0x03030303u, 0.0f), q1 = fields_h2((w.y >> (2 * k)) & 0x03030303u, 0.0f);
-        return GGQ_EMIT4(dl * q0.a - ml, dl * q0.b - ml, dl * q1.a - ml, dl * q1.b - ml);
+        return Fields{(w.x >> (2 * k)) & 0x03030303u, (w.y >> (2 * k)) & 0x03030303u, lds_ld4<4, LDS>(b + 80),
+                      (int32_t)(s & 15u), (int32_t)(s >> 4)};
     }
 };
 
 // dequant.py:197-219  [hmask 32][qs 64][scales 12][d]   out = rn(rn(d*(scale-32)) * (ql - (hb ? 0 : 4)))
 struct FmtQ3_K {
-    static constexpr int ID = 11, BS = 256, TS = 110, LDS_ALIGN = 2;
+    static constexpr int ID = 11, BS = 256, TS = 110, LDS_ALIGN = 2, KIND = K_SC, BIAS = 4;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int half = j >> 4, k = (j >> 2) & 3, c4 = j & 3, jj = j >> 1;
         const uint32_t lo = (lds_u8(b + 96 + (jj & 7)) >> (4 * (jj >> 3))) & 15u;
         const uint32_t hi = (lds_u8(b + 104 + (jj & 3)) >> (2 * (jj >> 2))) & 3u;
-        const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
-        const h2 dl = splat(lds_h(b + 108) * sc);
+        Fields f;
+        f.sc = (int32_t)(lo | (hi << 4)) - 32;
+        f.mn = 0;
+        f.dm = lds_u16(b + 108);
         const u32x2 w = lds_ld8<2, LDS>(b + 32 + 32 * half + 8 * c4);
         const u32x2 hm = lds_ld8<2, LDS>(b + 8 * c4);
         const int hs = j >> 2;
         // q = ql - 4*(1-hb) = (ql | hb << 2) - 4
-        const uint32_t t0 = ((w.x >> (2 * k)) & 0x03030303u) | (((hm.x >> hs) & 0x01010101u) << 2);
-        const uint32_t t1 = ((w.y >> (2 * k)) & 0x03030303u) | (((hm.y >> hs) & 0x01010101u) << 2);
-        const H2x2 q0 = fields_h2(t0, 4.0f), q1 = fields_h2(t1, 4.0f);
-        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+        f.t0 = ((w.x >> (2 * k)) & 0x03030303u) | (((hm.x >> hs) & 0x01010101u) << 2);
+        f.t1 = ((w.y >> (2 * k)) & 0x03030303u) | (((hm.y >> hs) & 0x01010101u) << 2);
+        return f;
     }
 };
 
 // dequant.py:258-285  [d][scales_h u16][scales_l 4][qs 128]   out = rn(rn(d*(scale-32)) * KVALUES[q])
 struct FmtIQ4_XS {
-    static constexpr int ID = 23, BS = 256, TS = 136, LDS_ALIGN = 8;
+    static constexpr int ID = 23, BS = 256, TS = 136, LDS_ALIGN = 8, KIND = K_SC, BIAS = 128;
     template <bool LDS>
-    GGQ_DEV static u32x4 chunk(const uint8_t* b, int j)
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
     {
         const int g = j >> 2, c4 = j & 3;
         const uint32_t lo = (lds_u8(b + 4 + (g >> 1)) >> (4 * (g & 1))) & 15u;
         const uint32_t hi = (lds_u16(b + 2) >> (2 * g)) & 3u;
-        const _Float16 sc = (_Float16)(int16_t)((int)(lo | (hi << 4)) - 32);
-        const h2 dl = splat(lds_h(b) * sc);
+        Fields f;
+        f.sc = (int32_t)(lo | (hi << 4)) - 32;
+        f.mn = 0;
+        f.dm = lds_u16(b);
         const u32x2 w = lds_ld8<8, LDS>(b + 8 + 16 * g + 8 * (c4 & 1));
         const int sh = (c4 >> 1) * 4;
-        const uint32_t t0 = (w.x >> sh) & 0x0F0F0F0Fu, t1 = (w.y >> sh) & 0x0F0F0F0Fu;
-        const H2x2 q0 = fields_h2(kvalues4(t0) ^ 0x80808080u, 128.0f), q1 = fields_h2(kvalues4(t1) ^ 0x80808080u, 128.0f);
-        return GGQ_EMIT4(dl * q0.a, dl * q0.b, dl * q1.a, dl * q1.b);
+        f.t0 = kvalues4((w.x >> sh) & 0x0F0F0F0Fu) ^ 0x80808080u;
+        f.t1 = kvalues4((w.y >> sh) & 0x0F0F0F0Fu) ^ 0x80808080u;
+        return f;
     }
 };
+
+// ============================================================================ arithmetic modes
+// The reference's `dtype` argument of the block functions (its dequant_dtype): None / float16 is the
+// stock path; float32 and bfloat16 cast d, m, dmin first and run the SAME op sequence in that dtype
+// (SURVEY.md section 8a "Precision modes").  Every reference op is one correctly rounded op here.
+enum : int { AR_F16 = 0, AR_BF16 = 1, AR_F32 = 2 };
+
+GGQ_DEV _Float16 h_of(uint32_t bits) { return __builtin_bit_cast(_Float16, (uint16_t)bits); }
+
+#define GGQ_EMIT4(EXPR_A0, EXPR_B0, EXPR_A1, EXPR_B1) \
+    u32x4 { as_u32(EXPR_A0), as_u32(EXPR_B0), as_u32(EXPR_A1), as_u32(EXPR_B1) }
+
+// All arithmetic works on QUADS: 4 consecutive elements = the 4 byte fields of one dword t.  A chunk
+// is two quads (t0, t1); the scale operands are common to both (the compiler shares them).
+
+// fp16 arithmetic: packed v_pk_mul_f16 / v_pk_add_f16, two elements per instruction; int -> fp16
+// through the exact 0x6400 trick.  Result: 4 fp16 values as 2 dwords.
+template <int KIND, int BIAS>
+GGQ_DEV u32x2 quad_f16(const Fields& f, uint32_t t)
+{
+    const H2x2 q = fields_h2(t, (float)BIAS);
+    if constexpr (KIND == K_D) {
+        const h2 d = bcast_lo(as_h2(f.dm));
+        return u32x2{as_u32(d * q.a), as_u32(d * q.b)};
+    } else if constexpr (KIND == K_DM) {
+        const h2 dm = as_h2(f.dm);
+        const h2 d = bcast_lo(dm), m = bcast_hi(dm);
+        return u32x2{as_u32(d * q.a + m), as_u32(d * q.b + m)};
+    } else if constexpr (KIND == K_SCMN) {
+        const h2 dlml = as_h2(f.dm) * ints_h2((uint32_t)f.sc | ((uint32_t)f.mn << 16), 0.0f);   // (d*sc, dmin*mn)
+        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+        return u32x2{as_u32(dl * q.a - ml), as_u32(dl * q.b - ml)};
+    } else {
+        const h2 dl = splat(h_of(f.dm) * (_Float16)(int16_t)f.sc);                               // v_cvt_f16_i16: exact
+        return u32x2{as_u32(dl * q.a), as_u32(dl * q.b)};
+    }
+}
+
+// fp32 / bf16 arithmetic share one body: values live in fp32 registers; RB = true rounds every
+// result to bf16 (RNE) -- exactly what torch's bf16 kernels do (fp32 op, then round).  Integers
+// (|q| <= 255) are exact in both dtypes.
+typedef __bf16 bf16_t;
+template <bool RB> GGQ_DEV float rnd(float x)
+{
+    if constexpr (RB) return (float)(bf16_t)x;      // gfx950: v_cvt_pk_bf16_f32, then << 16
+    else return x;
+}
+
+template <int KIND, int BIAS, bool RB>
+GGQ_DEV f32x4 quad_f32(const Fields& f, uint32_t t)
+{
+    float q[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = (float)((t >> (8 * i)) & 0xFFu) - (float)BIAS;   // v_cvt_f32_ubyteN, exact
+    const float d = rnd<RB>((float)h_of(f.dm));
+    if constexpr (KIND == K_D) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(d * q[i]);
+    } else if constexpr (KIND == K_DM) {
+        const float m = rnd<RB>((float)h_of(f.dm >> 16));
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(rnd<RB>(d * q[i]) + m);
+    } else if constexpr (KIND == K_SCMN) {
+        const float dmin = rnd<RB>((float)h_of(f.dm >> 16));
+        const float dl = rnd<RB>(d * (float)f.sc), ml = rnd<RB>(dmin * (float)f.mn);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(rnd<RB>(dl * q[i]) - ml);
+    } else {
+        const float dl = rnd<RB>(d * (float)f.sc);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(dl * q[i]);
+    }
+    return f32x4{r[0], r[1], r[2], r[3]};
+}
 
 // ============================================================================ output stage
 // The reference's dequantize_tensor ends with `.to(dtype)` (dequant.py:23): one cast of the fp16
@@ -379,30 +459,44 @@ GGQ_DEV u32x4 gload16(gcptr p)
     else return *(GGQ_GLOBAL const u32x4*)p;
 }
 
-GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh)
-{
-    const h2 v = as_h2(hh);
-    const uint32_t a = __builtin_bit_cast(uint32_t, (float)v.x), b = __builtin_bit_cast(uint32_t, (float)v.y);
-    // fp16 -> fp32 is exact; fp32 -> bf16 round-to-nearest-even, NaN kept quiet
-    auto rne = [](uint32_t u) -> uint32_t {
-        const uint32_t r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-        return ((u & 0x7FFFFFFFu) > 0x7F800000u) ? ((u >> 16) | 0x0040u) : r;
-    };
-    return rne(a) | (rne(b) << 16);
-}
+// The final `.to(dtype)` (dequant.py:23) is one RNE conversion, done in registers by the hardware
+// converters (v_cvt_f32_f16 is exact; v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 round to nearest even).
+typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+GGQ_DEV uint32_t pack_bf16(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2)); }
+GGQ_DEV uint32_t pack_f16(float a, float b) { return as_u32(h2{(_Float16)a, (_Float16)b}); }
+GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh) { const h2 v = as_h2(hh); return pack_bf16((float)v.x, (float)v.y); }
 
-template <int OUT, bool NT>
-GGQ_DEV void store_chunk(gptr out, uint64_t elem, u32x4 v)
+// How a wave lays its stores out.  Every store instruction must cover 1 KiB of CONTIGUOUS output
+// (64 lanes x 16 B: full 128-B lines; two half-line stores to the same lines measured 2x slower):
+//   2-byte outputs: a lane owns a whole chunk (8 elements = 16 B)            PIECES = 1
+//   fp32 output:    a lane owns a QUAD (4 elements = 16 B); the two lanes of a pair decode the
+//                   same chunk and each keeps one half                        PIECES = 2
+template <int OUT> struct Layout { static constexpr int PIECES = (OUT == OUT_F32) ? 2 : 1, ELEMS = 8 / PIECES; };
+
+// decode -> arithmetic (ARITH) -> cast (OUT) -> one 16-byte store; `piece` selects the quad for fp32 output
+template <class F, int ARITH, int OUT, bool NT>
+GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
 {
-    if constexpr (OUT == OUT_F16) {
-        gstore<NT>(out + elem * 2, v);
-    } else if constexpr (OUT == OUT_BF16) {
-        const u32x4 r{h2_to_bf16x2(v.x), h2_to_bf16x2(v.y), h2_to_bf16x2(v.z), h2_to_bf16x2(v.w)};
-        gstore<NT>(out + elem * 2, r);
+    constexpr int KIND = F::KIND, BIAS = F::BIAS;
+    constexpr bool RB = ARITH == AR_BF16;
+    if constexpr (OUT == OUT_F32) {
+        const uint32_t t = piece ? f.t1 : f.t0;
+        if constexpr (ARITH == AR_F16) {
+            const u32x2 v = quad_f16<KIND, BIAS>(f, t);
+            const h2 a = as_h2(v.x), b = as_h2(v.y);
+            gstore<NT>(out + elem * 4, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
+        } else {
+            gstore<NT>(out + elem * 4, quad_f32<KIND, BIAS, RB>(f, t));
+        }
+    } else if constexpr (ARITH == AR_F16) {
+        const u32x2 lo = quad_f16<KIND, BIAS>(f, f.t0), hi = quad_f16<KIND, BIAS>(f, f.t1);
+        if constexpr (OUT == OUT_F16) gstore<NT>(out + elem * 2, u32x4{lo.x, lo.y, hi.x, hi.y});
+        else gstore<NT>(out + elem * 2, u32x4{h2_to_bf16x2(lo.x), h2_to_bf16x2(lo.y), h2_to_bf16x2(hi.x), h2_to_bf16x2(hi.y)});
     } else {
-        const h2 a = as_h2(v.x), b = as_h2(v.y), c = as_h2(v.z), d = as_h2(v.w);
-        gstore<NT>(out + elem * 4, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
-        gstore<NT>(out + elem * 4 + 16, f32x4{(float)c.x, (float)c.y, (float)d.x, (float)d.y});
+        const f32x4 lo = quad_f32<KIND, BIAS, RB>(f, f.t0), hi = quad_f32<KIND, BIAS, RB>(f, f.t1);
+        if constexpr (OUT == OUT_BF16) gstore<NT>(out + elem * 2, u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)});
+        else gstore<NT>(out + elem * 2, u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)});
     }
 }
 
@@ -449,7 +543,7 @@ GGQ_DEV void store_throttle()
     if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
 }
 
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -461,12 +555,13 @@ struct Engine {
     static constexpr int UNITS = (GROUP_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;   // 16-B load units per group (max)
     static constexpr int NU = (UNITS + 63) / 64;       // per lane
     static constexpr int CHUNKS = G * CPB;
-    static constexpr int NCH = CHUNKS / 64;            // stores per lane per group
+    static constexpr int PIECES = Layout<OUT>::PIECES;  // lanes per chunk (2 for fp32 output: one quad each)
+    static constexpr int NCH = CHUNKS * PIECES / 64;   // stores per lane per group
     static constexpr int SLICE = NU * 64 * 16;         // LDS bytes per wave
     static constexpr int THREADS = WAVES * 64;
     static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
     static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
-    static_assert(CHUNKS % 64 == 0, "a group must be a whole number of 1 KiB store rows");
+    static_assert((CHUNKS * PIECES) % 64 == 0, "a group must be a whole number of 1 KiB store rows");
 
     // FULL = the whole group lies inside the tensor (wave-uniform): no per-lane bounds checks,
     // so the compiler batches the LDS reads of all NCH chunks.
@@ -499,12 +594,13 @@ struct Engine {
         const uint64_t b0 = w.lg * (uint64_t)G;
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
-            const int chunk = lane + 64 * s;
+            const int unit = lane + 64 * s;
+            const int chunk = unit / PIECES, piece = unit % PIECES;
             const int bl = chunk / CPB, j = chunk % CPB;
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
-                const u32x4 v = F::template chunk<true>(slice + a + bl * TS, j);
-                store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
+                const Fields f = F::template fields<true>(slice + a + bl * TS, j);
+                emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
             }
             if (s + 1 < NCH) store_throttle<THR>();
         }
@@ -519,12 +615,13 @@ struct Engine {
         const uint64_t b0 = w.lg * (uint64_t)G;
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
-            const int chunk = lane + 64 * s;
+            const int unit = lane + 64 * s;
+            const int chunk = unit / PIECES, piece = unit % PIECES;
             const int bl = chunk / CPB, j = chunk % CPB;
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
-                const u32x4 v = F::template chunk<false>((const uint8_t*)(w.packed + gb * (uint64_t)TS), j);
-                store_chunk<OUT, NTS>(w.out, gb * (uint64_t)BS + (uint64_t)(j * 8), v);
+                const Fields f = F::template fields<false>((const uint8_t*)(w.packed + gb * (uint64_t)TS), j);
+                emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
             }
         }
     }
@@ -568,17 +665,17 @@ struct Engine {
 };
 
 // one tensor, descriptor by value
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
 __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R>::run(total_groups, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, [&](uint64_t g) {
         uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;

@@ -8,12 +8,13 @@ Mirrored surface (reference file:line):
     dequantize_functions  {qtype: fn(blocks, block_size, type_size, dtype=None)}   dequant.py:287-301
 
 What runs where
-    * packed bytes on an AMD GPU, default arithmetic (dequant_dtype None / float16): the HIP
-      kernels -- bit-identical to the reference's eager fp16 op sequence.  The final
-      ``.to(dtype)`` of dequantize_tensor (dequant.py:23) is fused into the store for
-      dtype in {float16, bfloat16, float32}; any other dtype gets the same single torch cast.
+    * packed bytes on an AMD GPU: the HIP kernels -- bit-identical to the reference's eager op
+      sequence in all three arithmetic modes the nodes can select (dequant_dtype None / float16,
+      bfloat16, float32, or "target"; nodes.py:186).  The final ``.to(dtype)`` of
+      dequantize_tensor (dequant.py:23) is fused into the store for dtype in {float16, bfloat16,
+      float32}; any other dtype gets the same single torch cast.
     * BF16 "blocks" (dequant.py:61-62) are a pure bit reinterpretation -> one torch op on device.
-    * anything else -- CPU tensors, dequant_dtype float32/bfloat16 arithmetic, unknown qtypes --
+    * anything else -- CPU tensors, other dequant_dtype values, unknown qtypes --
       is NOT served here: :class:`GGQUnsupported` is raised.  There is deliberately no CPU or torch
       re-implementation in this package; ``install()`` (install.py) wires this module in front of
       the reference's own functions, which keep handling those cases.
@@ -29,7 +30,10 @@ Q = GGMLQuantizationType
 
 TORCH_COMPATIBLE_QTYPES = (None, Q.F32, Q.F16)
 
-_OUT_CODE = {torch.float16: _native.OUT_F16, torch.bfloat16: _native.OUT_BF16, torch.float32: _native.OUT_F32}
+_OUT_CODE = {torch.float16: _native.F16, torch.bfloat16: _native.BF16, torch.float32: _native.F32}
+# the reference's arithmetic dtype (`dtype` of the block functions = dequant_dtype) -> ggq_dtype
+_COMPUTE_CODE = {None: _native.F16, torch.float16: _native.F16, torch.bfloat16: _native.BF16, torch.float32: _native.F32}
+_COMPUTE_TORCH = {None: torch.float16, torch.float16: torch.float16, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
 
 
 class GGQUnsupported(NotImplementedError):
@@ -69,19 +73,28 @@ def _as_bytes(data):
     return data
 
 
-def _launch(qtype, data, n_blocks, out, out_code):
+def _launch(qtype, data, n_blocks, out, compute_code, out_code):
     dev = data.device
     if torch.cuda.current_device() != dev.index:
         with torch.cuda.device(dev):
-            return _launch(qtype, data, n_blocks, out, out_code)
+            return _launch(qtype, data, n_blocks, out, compute_code, out_code)
     stream = torch.cuda.current_stream(dev).cuda_stream   # order after the H2D copy, before F.linear
-    rc = _native.lib().ggq_dequant(int(qtype), data.data_ptr(), n_blocks, out.data_ptr(), out_code, stream)
+    rc = _native.lib().ggq_dequant(int(qtype), data.data_ptr(), n_blocks, out.data_ptr(), compute_code, out_code, stream)
     _native.check(rc, f"ggq_dequant({Q(int(qtype)).name})")
 
 
-def _dequant_hip(data, qtype, out_dtype):
-    """Packed device bytes -> flat dense tensor of ``out_dtype`` (fp16 math, then one cast)."""
+def _check_compute(dtype):
+    try:
+        return _COMPUTE_CODE[dtype]
+    except (KeyError, TypeError):
+        raise GGQUnsupported(f"dequant_dtype={dtype}: the HIP kernels compute in float16, bfloat16 or float32") from None
+
+
+def _dequant_hip(data, qtype, out_dtype, compute=None):
+    """Packed device bytes -> flat dense tensor of ``out_dtype``: the block function's op sequence in
+    the ``compute`` dtype (None = fp16), then one cast to ``out_dtype``, in one kernel."""
     key = _qtype_key(qtype)
+    compute_code = _check_compute(compute)
     if key not in HIP_QTYPES:
         raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r}")
     if not data.is_cuda:
@@ -91,7 +104,7 @@ def _dequant_hip(data, qtype, out_dtype):
     n_blocks = data.numel() // type_size                  # dequant.py:41
     out = torch.empty(n_blocks * block_size, dtype=out_dtype, device=data.device)
     if n_blocks:
-        _launch(key, data, n_blocks, out, _OUT_CODE[out_dtype])
+        _launch(key, data, n_blocks, out, compute_code, _OUT_CODE[out_dtype])
     return out
 
 
@@ -99,14 +112,14 @@ def dequantize(data, qtype, oshape, dtype=None):
     """Dequantize tensor back to usable shape/dtype (dequant.py:30-44).
 
     ``dtype`` is the reference's *arithmetic* dtype (its ``dequant_dtype``): None / float16 is the
-    stock fp16 path and returns float16.
+    stock fp16 path and returns float16; bfloat16 / float32 run the same op sequence in that dtype and
+    return it.
     """
     key = _qtype_key(qtype)
     if key == Q.BF16:
         return dequantize_blocks_BF16(_as_bytes(data), 1, 2, dtype).reshape(oshape)
-    if dtype not in (None, torch.float16):
-        raise GGQUnsupported(f"dequant_dtype={dtype}: only the default fp16 arithmetic has HIP kernels")
-    return _dequant_hip(data, qtype, torch.float16).reshape(oshape)
+    _check_compute(dtype)
+    return _dequant_hip(data, qtype, _COMPUTE_TORCH[dtype], compute=dtype).reshape(oshape)
 
 
 def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
@@ -119,12 +132,11 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
     key = _qtype_key(qtype)
     if key in HIP_QTYPES:
         dequant_dtype = dtype if dequant_dtype == "target" else dequant_dtype
-        if dequant_dtype not in (None, torch.float16):
-            raise GGQUnsupported(f"dequant_dtype={dequant_dtype}: only the default fp16 arithmetic has HIP kernels")
+        _check_compute(dequant_dtype)
         if dtype in _OUT_CODE:
-            # dequantize(...).to(dtype) with the cast fused into the kernel's store
-            return _dequant_hip(tensor.data, key, dtype).reshape(oshape)
-        return _dequant_hip(tensor.data, key, torch.float16).reshape(oshape).to(dtype)
+            # dequantize(..., dtype=dequant_dtype).to(dtype) with the cast fused into the kernel's store
+            return _dequant_hip(tensor.data, key, dtype, compute=dequant_dtype).reshape(oshape)
+        return _dequant_hip(tensor.data, key, _COMPUTE_TORCH[dequant_dtype], compute=dequant_dtype).reshape(oshape).to(dtype)
     if key == Q.BF16:
         return dequantize(tensor.data, key, oshape, dtype=dequant_dtype).to(dtype)
     raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r} "
@@ -140,13 +152,12 @@ def dequantize_blocks_BF16(blocks, block_size, type_size, dtype=None):
 
 def _make_block_fn(key):
     def fn(blocks, block_size, type_size, dtype=None):
-        """(n_blocks, type_size) uint8 -> (n_blocks, block_size) float16, on the GPU."""
-        if dtype not in (None, torch.float16):
-            raise GGQUnsupported(f"dtype={dtype}: only the default fp16 arithmetic has HIP kernels")
+        """(n_blocks, type_size) uint8 -> (n_blocks, block_size) of ``dtype`` (None: float16), on the GPU."""
+        _check_compute(dtype)
         bs, ts = GGML_QUANT_SIZES[key]
         if (block_size, type_size) != (bs, ts):
             raise ValueError(f"{key.name}: expected block geometry {(bs, ts)}, got {(block_size, type_size)}")
-        return _dequant_hip(blocks, key, torch.float16).reshape((-1, bs))
+        return _dequant_hip(blocks, key, _COMPUTE_TORCH[dtype], compute=dtype).reshape((-1, bs))
     fn.__name__ = fn.__qualname__ = f"dequantize_blocks_{key.name}"
     return fn
 

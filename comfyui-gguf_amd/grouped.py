@@ -10,18 +10,19 @@ import ctypes
 import torch
 
 from . import _native
-from .dequant import _OUT_CODE, _as_bytes, GGQUnsupported
+from .dequant import _OUT_CODE, _as_bytes, _check_compute, GGQUnsupported
 from .qtypes import GGML_QUANT_SIZES, GGMLQuantizationType, HIP_QTYPES
 
 
 class DequantPlan:
-    """``items``: iterable of (packed_bytes_tensor, qtype, logical_shape[, out_dtype]).
+    """``items``: iterable of (packed_bytes_tensor, qtype, logical_shape[, out_dtype[, dequant_dtype]]).
+    ``dequant_dtype`` is the reference's arithmetic dtype (None = fp16, or bfloat16 / float32).
 
     All tensors must live on one GPU.  Outputs are allocated here (``self.outputs``, same order,
     logical shapes) unless ``outputs`` supplies pre-allocated dense tensors.
     """
 
-    def __init__(self, items, out_dtype=torch.float16, outputs=None):
+    def __init__(self, items, out_dtype=torch.float16, outputs=None, dequant_dtype=None):
         items = [tuple(it) for it in items]
         if not items:
             raise ValueError("empty plan")
@@ -32,6 +33,8 @@ class DequantPlan:
         for i, it in enumerate(items):
             data, qtype, shape = it[:3]
             odt = it[3] if len(it) > 3 else out_dtype
+            cdt = it[4] if len(it) > 4 else dequant_dtype
+            cdt = odt if cdt == "target" else cdt
             key = GGMLQuantizationType(int(qtype))
             if key not in HIP_QTYPES:
                 raise GGQUnsupported(f"no HIP unpacker for {key.name}")
@@ -53,7 +56,7 @@ class DequantPlan:
                 raise ValueError("pre-allocated output does not match (dtype, numel, contiguity, device)")
             self._keep.append(data)
             self.outputs.append(out)
-            descs[i] = _native.ggq_desc(int(key), _OUT_CODE[odt], data.data_ptr(), out.data_ptr(), n_blocks)
+            descs[i] = _native.ggq_desc(int(key), _OUT_CODE[odt], data.data_ptr(), out.data_ptr(), n_blocks, _check_compute(cdt), 0)
         self.device = device
         self._plan = ctypes.c_void_p()
         with torch.cuda.device(device):

@@ -4,10 +4,10 @@
     install(ref_dequant, ref_ops)
 
 replaces ``dequantize`` and ``dequantize_tensor`` (reference dequant.py:15,30) -- and the name
-``ops.py`` imported at load time (reference ops.py:9) -- by wrappers that send GPU-resident,
-default-arithmetic requests to the HIP kernels and hand EVERYTHING ELSE to the reference's own
-original functions: CPU tensors at load time (loader.py:124,253,...), dequant_dtype float32 /
-bfloat16 arithmetic, qtypes without a kernel.  Nothing above ``dequantize_tensor`` changes:
+``ops.py`` imported at load time (reference ops.py:9) -- by wrappers that send GPU-resident
+requests (any dequant_dtype the nodes offer) to the HIP kernels and hand EVERYTHING ELSE to the
+reference's own original functions: CPU tensors at load time (loader.py:124,253,...), qtypes
+without a kernel.  Nothing above ``dequantize_tensor`` changes:
 ``GGMLTensor``, ``GGMLOps``, the loader and the nodes keep running the reference's code, so the
 "Unet Loader (GGUF)" node works unchanged.  ``uninstall()`` restores the originals.
 """
@@ -20,7 +20,7 @@ _installed = {}
 
 def _takes_hip(data, qtype, dequant_dtype):
     return (isinstance(data, torch.Tensor) and data.is_cuda and _hip.hip_supported(qtype)
-            and dequant_dtype in (None, torch.float16))
+            and dequant_dtype in _hip._COMPUTE_CODE)
 
 
 def install(ref_dequant, ref_ops=None, ref_loader=None):

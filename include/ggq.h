@@ -18,8 +18,9 @@
  *   - `qtype` is ggml's public type id (== int(gguf.GGMLQuantizationType.X)):
  *       Q4_0=2 Q4_1=3 Q5_0=6 Q5_1=7 Q8_0=8 Q2_K=10 Q3_K=11 Q4_K=12 Q5_K=13 Q6_K=14 IQ4_NL=20 IQ4_XS=23.
  *
- * Numerics: bit-identical to the reference's default fp16 path (dequant_dtype=None,
- * nodes.py:152-153): every torch op of a block function is one correctly rounded fp16 op here too.
+ * Numerics: bit-identical to the reference's eager op sequence -- in the default fp16 mode
+ * (dequant_dtype=None, nodes.py:152-153) and in the float32 / bfloat16 modes of the Advanced loader
+ * (nodes.py:186): every torch op of a block function is one correctly rounded op of that dtype here too.
  */
 #ifndef GGQ_H
 #define GGQ_H
@@ -34,15 +35,24 @@ typedef enum ggq_status {
     GGQ_OK = 0,
     GGQ_ERR_QTYPE = 1,   /* qtype has no HIP unpacker (caller keeps the reference path, dequant.py:24-28) */
     GGQ_ERR_ALIGN = 2,   /* packed or out not 16-byte aligned */
-    GGQ_ERR_ARG = 3,     /* NULL pointer with n_blocks > 0, bad out_dtype, bad descriptor table */
+    GGQ_ERR_ARG = 3,     /* NULL pointer with n_blocks > 0, bad compute/out dtype, bad descriptor table */
     GGQ_ERR_HIP = 4,     /* a HIP runtime call failed; ggq_last_hip_error() has the hipError_t */
     GGQ_ERR_NOMEM = 5    /* host or device allocation for a plan failed */
 } ggq_status;
 
-/* dtype of the dense output.  F16 is the reference's dequantize() result (dequant.py:30-44);
- * BF16 / F32 additionally fuse the single `.to(dtype)` cast that dequantize_tensor applies to
- * that fp16 result (dequant.py:23) -- same values as dequantize(...).to(dtype), one pass. */
-typedef enum ggq_out_dtype { GGQ_OUT_F16 = 0, GGQ_OUT_BF16 = 1, GGQ_OUT_F32 = 2 } ggq_out_dtype;
+/* Floating-point dtypes, used for two independent choices of dequantize_tensor (dequant.py:15-23):
+ *   compute_dtype  the reference's `dequant_dtype` (Advanced loader, nodes.py:186): the dtype the block
+ *                  function's op sequence runs in.  F16 = the stock path (dequant_dtype None); BF16 /
+ *                  F32 first cast d, m, dmin to that dtype and run the SAME ops in it (dequant.py:67,
+ *                  75-76, ...), every op rounded once in that dtype.  "target" = pass out_dtype.
+ *   out_dtype      the dtype of the dense result: the single `.to(dtype)` cast dequantize_tensor applies
+ *                  to the block function's result (dequant.py:23), fused into the store -- same values
+ *                  as dequantize(..., dtype=compute_dtype).to(out_dtype), one pass over memory. */
+typedef enum ggq_dtype { GGQ_F16 = 0, GGQ_BF16 = 1, GGQ_F32 = 2 } ggq_dtype;
+/* older spellings of the out_dtype values */
+#define GGQ_OUT_F16 GGQ_F16
+#define GGQ_OUT_BF16 GGQ_BF16
+#define GGQ_OUT_F32 GGQ_F32
 
 /* ---- queries ------------------------------------------------------------------------------- */
 
@@ -68,10 +78,12 @@ int ggq_abi_version(void);
  * Replaces: dequantize(data, qtype, oshape, dtype=None) (dequant.py:30-44) -- the framing
  * (n_blocks = numel // type_size, output element b*block_size+j = block b element j) is the
  * caller's reshape; and dequantize_functions[qtype](blocks, block_size, type_size) (dequant.py:43).
+ * With compute_dtype / out_dtype it also covers dequantize_tensor(tensor, dtype, dequant_dtype)
+ * (dequant.py:15-23): dequantize(..., dtype=compute_dtype).to(out_dtype).
  * n_blocks == 0 is a no-op that returns GGQ_OK. */
-int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int out_dtype, void* hip_stream);
+int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* hip_stream);
 
-/* Same with out_dtype = GGQ_OUT_F16 (the reference's own result dtype). */
+/* Same with compute_dtype = out_dtype = GGQ_F16 (the stock node: dequantize(data, qtype, oshape)). */
 int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream);
 
 /* ---- many tensors, one call (the weight set of a model) ------------------------------------- */
@@ -79,21 +91,23 @@ int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_
 /* One entry per tensor.  Replaces: one dequantize_tensor() call per layer (ops.py:177). */
 typedef struct ggq_desc {
     int32_t qtype;
-    int32_t out_dtype;      /* ggq_out_dtype */
+    int32_t out_dtype;      /* ggq_dtype of the dense result */
     const void* packed;     /* device, 16-B aligned */
     void* out;              /* device, 16-B aligned */
     uint64_t n_blocks;
+    int32_t compute_dtype;  /* ggq_dtype the arithmetic runs in (GGQ_F16 = stock path) */
+    int32_t reserved;       /* must be 0 */
 } ggq_desc;
 
 typedef struct ggq_plan ggq_plan;
 
 /* Build a launch plan for `n` tensors on the current device: descriptors are grouped by
- * (qtype, out_dtype), their work is prefix-summed and the tables are copied to device memory
+ * (qtype, compute_dtype, out_dtype), their work is prefix-summed and the tables are copied to device memory
  * once (synchronous, load-time).  Pointers are captured, not the bytes: the plan stays valid
  * while the tensors keep their addresses (packed weights resident in HBM). */
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out);
 
-/* Enqueue the whole plan on `hip_stream`: one kernel per (qtype, out_dtype) present. */
+/* Enqueue the whole plan on `hip_stream`: one kernel per (qtype, compute_dtype, out_dtype) present. */
 int ggq_plan_launch(const ggq_plan* plan, void* hip_stream);
 
 /* Algorithmic bytes one launch moves (packed read + dense write), and its kernel count. */

@@ -42,6 +42,8 @@ def lib():
         L.ggq_oracle_bf16_to_f32.argtypes = [u8p, ctypes.c_uint64, u32p]
         L.ggq_oracle_cast_f16_to_bf16.argtypes = [u16p, ctypes.c_uint64, u16p]
         L.ggq_oracle_cast_f16_to_f32.argtypes = [u16p, ctypes.c_uint64, f32p]
+        L.ggq_oracle_cast_f32_to_bf16.argtypes = [f32p, ctypes.c_uint64, u16p]
+        L.ggq_oracle_cast_f32_to_f16.argtypes = [f32p, ctypes.c_uint64, u16p]
         L.ggq_oracle_block_size.argtypes = [ctypes.c_int]
         L.ggq_oracle_type_size.argtypes = [ctypes.c_int]
         L.ggq_oracle_d2h.argtypes = [ctypes.c_double]
@@ -126,6 +128,63 @@ def cast_f16_to_bf16_bits(h):
     out = np.empty_like(h)
     L.ggq_oracle_cast_f16_to_bf16(_ptr(h, ctypes.c_uint16), h.size, _ptr(out, ctypes.c_uint16))
     return out
+
+
+def cast_f32_to_bf16_bits(x):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty(x.size, dtype=np.uint16)
+    L.ggq_oracle_cast_f32_to_bf16(_ptr(x, ctypes.c_float), x.size, _ptr(out, ctypes.c_uint16))
+    return out
+
+
+def cast_f32_to_f16_bits(x):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    out = np.empty(x.size, dtype=np.uint16)
+    L.ggq_oracle_cast_f32_to_f16(_ptr(x, ctypes.c_float), x.size, _ptr(out, ctypes.c_uint16))
+    return out
+
+
+def dequant_tensor(qtype, packed, compute="f16", out="f16"):
+    """dequantize_tensor(tensor, dtype=out, dequant_dtype=compute) (dequant.py:15-23):
+    dequantize(..., dtype=compute).to(out).  compute / out in {"f16", "bf16", "f32"}.
+    Returns np.float32 for out == "f32", else the 16-bit patterns (np.uint16)."""
+    if compute == "f16":
+        h = dequant_f16(qtype, packed)
+        if out == "f16":
+            return h.view(np.uint16)
+        if out == "bf16":
+            return cast_f16_to_bf16_bits(h)
+        return h.astype(np.float32)                      # exact
+    if compute == "f32":
+        x = dequant_f32(qtype, packed)
+    elif compute == "bf16":
+        b = dequant_bf16_bits(qtype, packed)
+        if out == "bf16":
+            return b
+        x = (b.astype(np.uint32) << 16).view(np.float32)  # exact
+    else:
+        raise ValueError(compute)
+    if out == "f32":
+        return x
+    return cast_f32_to_bf16_bits(x) if out == "bf16" else cast_f32_to_f16_bits(x)
+
+
+def canon_nan(bits_or_f32):
+    """NaN payloads (and NaN signs) are not part of parity: map every NaN to one pattern.
+    uint16 input is ambiguous between fp16 and bf16, so use canon_nan_f16 / canon_nan_bf16 for those."""
+    a = np.ascontiguousarray(bits_or_f32)
+    assert a.dtype == np.float32
+    bits = a.view(np.uint32).copy()
+    bits[(bits & 0x7FFFFFFF) > 0x7F800000] = 0x7FC00000
+    return bits
+
+
+def canon_nan_bf16(a):
+    bits = np.ascontiguousarray(a).view(np.uint16).copy()
+    bits[(bits & 0x7FFF) > 0x7F80] = 0x7FC0
+    return bits
 
 
 def canon_nan_f16(a):

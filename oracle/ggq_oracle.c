@@ -365,6 +365,17 @@ void ggq_oracle_cast_f16_to_f32(const uint16_t *in, uint64_t n, float *out)
     for (uint64_t i = 0; i < n; i++) out[i] = h2f(in[i]);
 }
 
+/* ... and for an fp32 / bf16 result (dequant_dtype float32 / bfloat16): torch casts fp32 -> bf16 and
+ * fp32 -> fp16 with round-to-nearest-even; bf16 -> anything goes through the exact bf16 -> fp32 widening */
+void ggq_oracle_cast_f32_to_bf16(const float *in, uint64_t n, uint16_t *out)
+{
+    for (uint64_t i = 0; i < n; i++) out[i] = f2bf(in[i]);
+}
+void ggq_oracle_cast_f32_to_f16(const float *in, uint64_t n, uint16_t *out)
+{
+    for (uint64_t i = 0; i < n; i++) out[i] = d2h((double)in[i]);
+}
+
 /* exposed so tests can check the soft-float helpers against numpy */
 uint16_t ggq_oracle_d2h(double x) { return d2h(x); }
 double   ggq_oracle_h2d(uint16_t h) { return h2d(h); }

@@ -101,7 +101,7 @@ static int parity()
                 uint64_t bad[3] = {0, 0, 0};
                 for (int od = 0; od < 3; od++) {
                     HIP_CHECK(hipMemset(dout, 0xCD, n * bs * 4 + 256));
-                    const int rc = ggq_dequant(q.id, dp, n, dout, od, nullptr);
+                    const int rc = ggq_dequant(q.id, dp, n, dout, GGQ_F16, od, nullptr);
                     if (rc) { printf("PARITY %s: ggq_dequant rc=%d (%s)\n", q.name, rc, ggq_strerror(rc)); failures++; continue; }
                     HIP_CHECK(hipDeviceSynchronize());
                     uint8_t guard[256];

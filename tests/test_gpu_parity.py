@@ -87,6 +87,75 @@ def test_against_oracle_ragged_sizes(pkg, name, mode):
         assert np.array_equal(g32.view(np.uint32)[~both_nan], w32.view(np.uint32)[~both_nan]), (name, n)
 
 
+_TORCH = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def _canon(a, kind):
+    a = np.ascontiguousarray(a).reshape(-1)
+    if kind == "f32":
+        return oracle.canon_nan(a.view(np.float32))
+    return oracle.canon_nan_f16(a) if kind == "f16" else oracle.canon_nan_bf16(a)
+
+
+def _raw(t):
+    return t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int16).cpu().numpy().reshape(-1)
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("compute", ["bf16", "f32"])
+def test_dequant_dtype_modes_golden(pkg, golden_dir, name, compute):
+    """dequant_dtype = float32 / bfloat16 (Advanced loader, nodes.py:186): the block function's op
+    sequence in that dtype, bit-exact to the reference's own output (committed golden vectors)."""
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    q = pkg.qtypes.Q[name]
+    blocks = g["blocks"][g["sub"]]
+    n, bs = blocks.shape[0], pkg.qtypes.block_geometry(q)[0]
+    data = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    out = pkg.dequant.dequantize(data, q, (n, bs), dtype=_TORCH[compute])    # dequant.py:30, dtype = dequant_dtype
+    assert out.dtype == _TORCH[compute] and tuple(out.shape) == (n, bs)
+    want = g["out_f32"] if compute == "f32" else g["out_bf16"]
+    assert np.array_equal(_canon(_raw(out), compute), _canon(want, compute))
+    fn = pkg.dequant.dequantize_functions[q]                                 # dequant.py:43 with a dtype argument
+    out2 = fn(data.reshape(n, -1), *pkg.qtypes.block_geometry(q), _TORCH[compute])
+    assert out2.dtype == _TORCH[compute] and np.array_equal(_raw(out2), _raw(out))
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("mode", ["signed", "adversarial"])
+def test_dequant_tensor_all_dtype_combinations(pkg, name, mode):
+    """dequantize_tensor(tensor, dtype, dequant_dtype) for every (dequant_dtype, dtype) pair the nodes can
+    produce, incl. "target": == dequantize(..., dtype=dequant_dtype).to(dtype) of the oracle, bit for bit,
+    across group boundaries and a ragged tail."""
+    q = pkg.qtypes.Q[name]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    G = 64 if bs == 32 else 8
+    for n in (1, G + 1, 7 * G + 5):
+        blocks = pkg.synth.make_blocks(q, n, seed=1000 + n, mode=mode)
+        t = _carrier(pkg, blocks, q)
+        for compute in ("f16", "bf16", "f32"):
+            for out in ("f16", "bf16", "f32"):
+                want = oracle.dequant_tensor(q, blocks, compute, out)
+                got = pkg.dequant.dequantize_tensor(t, _TORCH[out], dequant_dtype=None if compute == "f16" else _TORCH[compute])
+                assert got.dtype == _TORCH[out] and tuple(got.shape) == (n, bs)
+                assert np.array_equal(_canon(_raw(got), out), _canon(want, out)), (name, n, compute, out)
+                if compute == out:
+                    tgt = pkg.dequant.dequantize_tensor(t, _TORCH[out], dequant_dtype="target")
+                    assert np.array_equal(_raw(tgt), _raw(got))
+
+
+@pytest.mark.parametrize("name", ["Q4_K", "Q6_K", "Q8_0"])
+@pytest.mark.parametrize("compute", ["bf16", "f32"])
+def test_dequant_dtype_modes_full_size(pkg, name, compute):
+    """Shape C (3072x12288) at full size in the bf16 / fp32 arithmetic modes, "target" output."""
+    q = pkg.qtypes.Q[name]
+    packed = pkg.synth.make_tensor_bytes(q, (3072, 12288), seed=12, mode="signed")
+    t = pkg.ops.GGMLTensor(torch.from_numpy(packed).to(DEV), tensor_type=q, tensor_shape=(3072, 12288))
+    got = pkg.dequant.dequantize_tensor(t, _TORCH[compute], dequant_dtype="target")
+    want = oracle.dequant_tensor(q, packed, compute, compute)
+    u = np.uint32 if compute == "f32" else np.uint16
+    assert np.array_equal(_raw(got).view(u), want.view(u))                   # signed nominal scales: no NaN, raw bits
+
+
 def test_trailing_bytes_and_empty(pkg):
     """n_blocks = numel // type_size (dequant.py:41); an empty tensor is legal."""
     q = pkg.qtypes.Q.Q5_K
@@ -212,7 +281,17 @@ def test_plan_mixed_qtypes_matches_per_tensor(pkg):
     for i, (out, want) in enumerate(zip(outs2, wants)):
         ref = oracle.cast_f16_to_bf16_bits(want) if i % 2 else want
         assert np.array_equal(_bits16(out), ref)
-    plan.close(); plan2.close()
+    # mixed arithmetic modes in one plan (dequant_dtype per tensor)
+    kinds = ["f16", "bf16", "f32"]
+    plan3 = pkg.grouped.DequantPlan([it + (_TORCH[kinds[(i + 1) % 3]], None if i % 3 == 0 else _TORCH[kinds[i % 3]]) for i, it in enumerate(items)])
+    assert plan3.kernels == len(items) - 1          # only the two Q8_0 entries share (qtype, compute, out)
+    outs3 = plan3.launch()
+    torch.cuda.synchronize()
+    for i, ((q, shape), out) in enumerate(zip(spec, outs3)):
+        packed = items[i][0].cpu().numpy()
+        want = oracle.dequant_tensor(q, packed, kinds[i % 3], kinds[(i + 1) % 3])
+        assert np.array_equal(_canon(_raw(out), kinds[(i + 1) % 3]), _canon(want, kinds[(i + 1) % 3])), (q, shape, i)
+    plan.close(); plan2.close(); plan3.close()
 
 
 def test_ggml_linear_forward_is_the_reference_call_chain(pkg):
@@ -233,7 +312,7 @@ def test_unsupported_requests_raise(pkg):
     dq, Q = pkg.dequant, pkg.qtypes.Q
     data = torch.zeros(144 * 4, dtype=torch.uint8, device=DEV)
     with pytest.raises(dq.GGQUnsupported):
-        dq.dequantize(data, Q.Q4_K, (4, 256), dtype=torch.bfloat16)          # bf16 ARITHMETIC mode: reference's job
+        dq.dequantize(data, Q.Q4_K, (4, 256), dtype=torch.float64)           # not an arithmetic mode of the kernels
     with pytest.raises(dq.GGQUnsupported):
         dq.dequantize(data, Q.IQ2_XXS, (4, 256))
     with pytest.raises(dq.GGQUnsupported):

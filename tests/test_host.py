@@ -71,16 +71,19 @@ def test_c_abi_queries_and_argument_checks(pkg):
         assert lib.ggq_supported(bad) == 0 and lib.ggq_block_size(bad) == 0 and lib.ggq_type_size(bad) == 0
     assert lib.ggq_strerror(0) == b"ok" and b"aligned" in lib.ggq_strerror(nat.GGQ_ERR_ALIGN)
     q4k = int(qt.Q.Q4_K)
-    assert lib.ggq_dequant(99, 16, 1, 16, 0, None) == nat.GGQ_ERR_QTYPE
-    assert lib.ggq_dequant(q4k, 16, 1, 16, 7, None) == nat.GGQ_ERR_ARG          # bad out dtype
-    assert lib.ggq_dequant(q4k, None, 1, 16, 0, None) == nat.GGQ_ERR_ARG         # NULL packed
-    assert lib.ggq_dequant(q4k, 24, 1, 32, 0, None) == nat.GGQ_ERR_ALIGN         # packed % 16 != 0
-    assert lib.ggq_dequant(q4k, 32, 1, 8, 0, None) == nat.GGQ_ERR_ALIGN          # out % 16 != 0
-    assert lib.ggq_dequant(q4k, None, 0, None, 0, None) == nat.GGQ_OK            # empty tensor: no-op
+    assert lib.ggq_dequant(99, 16, 1, 16, 0, 0, None) == nat.GGQ_ERR_QTYPE
+    assert lib.ggq_dequant(q4k, 16, 1, 16, 0, 7, None) == nat.GGQ_ERR_ARG       # bad out dtype
+    assert lib.ggq_dequant(q4k, 16, 1, 16, 3, 0, None) == nat.GGQ_ERR_ARG       # bad compute dtype
+    assert lib.ggq_dequant(q4k, None, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG      # NULL packed
+    assert lib.ggq_dequant(q4k, 24, 1, 32, 0, 0, None) == nat.GGQ_ERR_ALIGN      # packed % 16 != 0
+    assert lib.ggq_dequant(q4k, 32, 1, 8, 2, 1, None) == nat.GGQ_ERR_ALIGN       # out % 16 != 0
+    assert lib.ggq_dequant(q4k, None, 0, None, 1, 2, None) == nat.GGQ_OK         # empty tensor: no-op
     assert lib.ggq_dequant_f16(99, 16, 1, 16, None) == nat.GGQ_ERR_QTYPE
     plan = ctypes.c_void_p()
-    bad = (nat.ggq_desc * 1)(nat.ggq_desc(99, 0, 16, 16, 1))
+    bad = (nat.ggq_desc * 1)(nat.ggq_desc(99, 0, 16, 16, 1, 0, 0))
     assert lib.ggq_plan_create(bad, 1, ctypes.byref(plan)) == nat.GGQ_ERR_QTYPE and not plan.value
+    bad = (nat.ggq_desc * 1)(nat.ggq_desc(q4k, 0, 16, 16, 1, 5, 0))
+    assert lib.ggq_plan_create(bad, 1, ctypes.byref(plan)) == nat.GGQ_ERR_ARG and not plan.value
     assert lib.ggq_plan_launch(None, None) == nat.GGQ_ERR_ARG
     assert lib.ggq_plan_bytes(None) == 0
     with pytest.raises(nat.GGQNativeError, match="aligned"):
@@ -127,10 +130,12 @@ def test_dispatch_and_error_behaviour_on_cpu(pkg, golden_dir):
         dq.dequantize_tensor(q, torch.float16)
     with pytest.raises(dq.GGQUnsupported):
         dq.dequantize(q.data, Q.Q4_K, (1, 256))
-    with pytest.raises(dq.GGQUnsupported, match="float32"):
+    with pytest.raises(dq.GGQUnsupported, match="cpu"):                  # any arithmetic mode: GPU-resident bytes only
         dq.dequantize(q.data, Q.Q4_K, (1, 256), dtype=torch.float32)
-    with pytest.raises(dq.GGQUnsupported, match="float32"):
-        dq.dequantize_tensor(q, torch.float32, dequant_dtype="target")
+    with pytest.raises(dq.GGQUnsupported, match="float64"):              # dequant_dtype the kernels do not compute in
+        dq.dequantize(q.data, Q.Q4_K, (1, 256), dtype=torch.float64)
+    with pytest.raises(dq.GGQUnsupported, match="float64"):
+        dq.dequantize_tensor(q, torch.float64, dequant_dtype="target")
     odd = _Carrier(torch.zeros(66, dtype=torch.uint8), Q.IQ2_XXS, torch.Size((256,)))
     with pytest.raises(dq.GGQUnsupported, match="IQ2_XXS"):
         dq.dequantize_tensor(odd, torch.float16)
@@ -257,7 +262,7 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
         assert torch.equal(before, after)
         want = torch.from_numpy(oracle.dequant_f16(Q.Q4_K, blocks).reshape(8, 512).copy()).float()
         assert torch.equal(after, torch.nn.functional.linear(x, want))
-        # an out-of-scope arithmetic mode also falls through to the reference, not to an error
+        # CPU-resident bytes in another arithmetic mode: the reference's own code, not an error
         w32 = rd.dequantize_tensor(weight, torch.float32, dequant_dtype=torch.float32)
         assert w32.dtype == torch.float32
         assert np.array_equal(w32.numpy().reshape(-1), oracle.dequant_f32(Q.Q4_K, blocks))
