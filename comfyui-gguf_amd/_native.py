@@ -17,8 +17,8 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libggq_hip.so")
-SOURCES = [os.path.join(CSRC, "ggq_capi.hip")]
-HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(ROOT, "include", "ggq.h")]
+SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip")]
+HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
 ABI_VERSION = 2
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
@@ -28,7 +28,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # fused multiply-add mnemonics that must not appear in the dequant kernels
 _FMA_RE = re.compile(r"\b(v_(?:pk_)?(?:fma|fmac)_\w+|v_mad_(?:f16|f32|legacy_f\w+|mix\w*|mixlo\w*|mixhi\w*)\w*)")
 
-GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM = range(6)
+GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM, GGQ_ERR_IO, GGQ_ERR_FORMAT = range(8)
 F16, BF16, F32 = 0, 1, 2          # ggq_dtype: compute and out dtypes
 OUT_F16, OUT_BF16, OUT_F32 = F16, BF16, F32
 
@@ -39,6 +39,23 @@ _u64, _u32, _int, _vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c
 class ggq_desc(ctypes.Structure):
     _fields_ = [("qtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("packed", _vp), ("out", _vp), ("n_blocks", _u64),
                 ("compute_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+GGUF_MAX_DIMS = 8
+
+
+class ggq_gguf_info(ctypes.Structure):
+    _fields_ = [("version", _u32), ("alignment", _u32), ("n_tensors", _u64), ("n_kv", _u64), ("data_offset", _u64),
+                ("data_bytes", _u64), ("file_bytes", _u64), ("base", _vp)]
+
+
+class ggq_gguf_tensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("qtype", ctypes.c_int32), ("n_dims", _u32), ("dims", _u64 * GGUF_MAX_DIMS),
+                ("offset", _u64), ("nbytes", _u64), ("n_elements", _u64)]
+
+
+class ggq_gguf_kv(ctypes.Structure):
+    _fields_ = [("key", ctypes.c_char_p), ("type", _u32), ("elem_type", _u32), ("count", _u64), ("data", _vp), ("nbytes", _u64)]
 
 
 SYMBOLS = {
@@ -55,6 +72,17 @@ SYMBOLS = {
     "ggq_plan_bytes": (_u64, [_vp]),
     "ggq_plan_kernels": (_u32, [_vp]),
     "ggq_plan_destroy": (None, [_vp]),
+    # include/ggq_gguf.h
+    "ggq_gguf_open": (_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    "ggq_gguf_close": (None, [_vp]),
+    "ggq_gguf_get_info": (_int, [_vp, ctypes.POINTER(ggq_gguf_info)]),
+    "ggq_gguf_get_tensor": (_int, [_vp, _u64, ctypes.POINTER(ggq_gguf_tensor)]),
+    "ggq_gguf_find_kv": (ctypes.c_int64, [_vp, ctypes.c_char_p]),
+    "ggq_gguf_get_kv": (_int, [_vp, _u64, ctypes.POINTER(ggq_gguf_kv)]),
+    "ggq_gguf_kv_string": (_int, [_vp, _u64, _u64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_u64)]),
+    "ggq_ggml_type_geometry": (_int, [_int, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "ggq_gguf_upload": (_int, [_vp, _vp, _u64, _u64, _int, _u64, _vp]),
+    "ggq_gguf_upload_release": (None, []),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 // Host side is plain C++ on the HIP runtime; nothing here knows about torch.
 #include "ggq_device.hpp"
 #include "../../include/ggq.h"
+#include "../../include/ggq_gguf.h"
 
 #include <new>
 #include <vector>
@@ -146,7 +147,9 @@ const char* ggq_strerror(int status)
     case GGQ_ERR_ALIGN: return "packed/out pointer is not 16-byte aligned";
     case GGQ_ERR_ARG: return "invalid argument";
     case GGQ_ERR_HIP: return "HIP runtime error (see ggq_last_hip_error)";
-    case GGQ_ERR_NOMEM: return "out of memory building a plan";
+    case GGQ_ERR_NOMEM: return "out of memory (host, pinned or device allocation)";
+    case GGQ_ERR_IO: return "file I/O error (open / mmap / pread)";
+    case GGQ_ERR_FORMAT: return "not a GGUF v2/v3 file, or truncated / inconsistent";
     default: return "unknown ggq status";
     }
 }

@@ -1,0 +1,284 @@
+"""The GGUF container reader (include/ggq_gguf.h, native) and the gguf_sd_loader mirror, on CPU.
+
+Parity note: the reference reads these files through the third-party gguf.GGUFReader (loader.py:55;
+gguf>=0.13.0, unpinned, absent from /root/reference and from this image), and ships no .gguf file and
+no loader test.  The parser is therefore pinned to the PUBLIC container layout: (a) a byte-for-byte
+hand-assembled file (below), (b) an independent pure-python writer (tests/gguf_writer.py); the loader
+mirror is checked against the behaviour read off loader.py:51-141 line by line."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from gguf_writer import (ARRAY, BOOL, FLOAT32, FLOAT64, INT8, INT16, INT32, INT64, STRING, UINT8, UINT16, UINT32, UINT64,
+                         GGUFWriter)
+
+
+def _s(b):
+    return struct.pack("<Q", len(b)) + b
+
+
+# A complete GGUF v3 file assembled by hand from the layout in include/ggq_gguf.h:
+# 2 KV pairs, 2 tensors (F32 [3] and Q8_0 [32 x 2]), alignment 32.
+_HAND_HEAD = (
+    b"GGUF" + struct.pack("<I", 3) + struct.pack("<Q", 2) + struct.pack("<Q", 2)
+    + _s(b"general.architecture") + struct.pack("<I", 8) + _s(b"flux")
+    + _s(b"answer") + struct.pack("<I", 4) + struct.pack("<I", 42)
+    + _s(b"bias") + struct.pack("<I", 1) + struct.pack("<Q", 3) + struct.pack("<I", 0) + struct.pack("<Q", 0)
+    + _s(b"w.weight") + struct.pack("<I", 2) + struct.pack("<Q", 32) + struct.pack("<Q", 2) + struct.pack("<I", 8) + struct.pack("<Q", 32)
+)
+_HAND_PAD = (-len(_HAND_HEAD)) % 32
+_HAND_BIAS = struct.pack("<3f", 1.0, -2.5, 3.25)
+_HAND_Q8 = bytes(range(68))
+HAND_FILE = _HAND_HEAD + b"\0" * _HAND_PAD + _HAND_BIAS + b"\0" * 20 + _HAND_Q8
+
+
+@pytest.fixture()
+def gf(pkg):
+    return pkg.gguf_file
+
+
+def _write(tmp_path, data, name="t.gguf"):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return str(p)
+
+
+def test_hand_assembled_file(pkg, gf, tmp_path):
+    Q = pkg.qtypes.Q
+    with gf.GGUFFile(_write(tmp_path, HAND_FILE)) as f:
+        assert (f.version, f.alignment, f.n_kv, len(f.tensors)) == (3, 32, 2, 2)
+        assert f.data_offset == len(_HAND_HEAD) + _HAND_PAD and f.data_bytes == 32 + 68
+        assert f.keys() == ["general.architecture", "answer"]
+        assert f.get_field("general.architecture") == gf.GGUFField("general.architecture", [gf.STRING], "flux")
+        assert f.get_field("answer").value == 42 and f.get_field("answer").types == [gf.UINT32]
+        assert f.get_field("nope") is None
+        b, w = f.tensors
+        assert (b.name, b.tensor_type, b.shape, b.offset, b.nbytes, b.n_elements) == ("bias", Q.F32, (3,), 0, 12, 3)
+        assert (w.name, w.tensor_type, w.shape, w.offset, w.nbytes, w.n_elements) == ("w.weight", Q.Q8_0, (32, 2), 32, 68, 64)
+        assert b.data.dtype == torch.uint8 and b.data.view(torch.float32).tolist() == [1.0, -2.5, 3.25]
+        assert bytes(w.data.numpy()) == _HAND_Q8
+    with pytest.raises(ValueError, match="closed"):
+        f.get_field("answer")
+    assert bytes(w.data.numpy()) == _HAND_Q8          # CPU views outlive the handle (own mapping)
+
+
+def test_every_value_type_round_trips(pkg, gf, tmp_path):
+    w = GGUFWriter(arch="sd3")
+    scalars = [("u8", UINT8, 200), ("i8", INT8, -7), ("u16", UINT16, 65535), ("i16", INT16, -3), ("u32", UINT32, 4000000000),
+               ("i32", INT32, -5), ("f32", FLOAT32, 1.5), ("b", BOOL, True), ("u64", UINT64, 2**63 + 5), ("i64", INT64, -2**62),
+               ("f64", FLOAT64, 1e-300), ("s", STRING, "héllo ✓"), ("empty", STRING, "")]
+    for k, t, v in scalars:
+        w.add(k, t, v)
+    w.add("arr.i32", ARRAY, [3072, 64, -1], INT32)
+    w.add("arr.f32", ARRAY, [0.5, -0.25], FLOAT32)
+    w.add("arr.str", ARRAY, ["<pad>", "", "▁the", "x" * 300], STRING)
+    w.add("arr.empty", ARRAY, [], UINT8)
+    w.add("arr.bool", ARRAY, [True, False, True], BOOL)
+    with gf.GGUFFile(w.write(str(tmp_path / "kv.gguf"))) as f:
+        assert f.n_kv == len(scalars) + 6 and len(f.tensors) == 0 and f.data_bytes == 0
+        for k, t, v in scalars:
+            fld = f.get_field(k)
+            assert fld.types == [t] and fld.value == v and type(fld.value) is type(v), k
+        assert f.get_field("arr.i32") == gf.GGUFField("arr.i32", [ARRAY, INT32], (3072, 64, -1))
+        assert f.get_field("arr.f32").value == (0.5, -0.25)
+        assert f.get_field("arr.str").value == ("<pad>", "", "▁the", "x" * 300) and f.get_field("arr.str").types == [ARRAY, STRING]
+        assert f.get_field("arr.empty").value == () and f.get_field("arr.bool").value == (True, False, True)
+        # the reference's accessors (loader.py:26-49)
+        ld = pkg.loader
+        assert ld.get_field(f, "general.architecture", str) == "sd3" and ld.get_field(f, "i32", int) == -5
+        assert ld.get_field(f, "f32", float) == 1.5 and ld.get_field(f, "b", bool) is True and ld.get_field(f, "zz", int) is None
+        with pytest.raises(TypeError, match="expected string"):
+            ld.get_field(f, "u8", str)
+        with pytest.raises(TypeError, match="Unknown field type"):
+            ld.get_field(f, "u8", bytes)
+        assert ld.get_list_field(f, "arr.str", str)[2] == "▁the" and ld.get_list_field(f, "arr.f32", float) == (0.5, -0.25)
+        assert ld.get_list_field(f, "arr.i32", int) == (3072, 64, -1) and ld.get_list_field(f, "zz", int) is None
+
+
+@pytest.mark.parametrize("alignment,version", [(32, 3), (64, 3), (256, 2), (8, 3)])
+def test_tensor_table_offsets_and_views(pkg, gf, tmp_path, alignment, version):
+    Q, synth = pkg.qtypes.Q, pkg.synth
+    w = GGUFWriter(arch="flux", alignment=alignment, version=version)
+    spec = [("a.weight", Q.Q4_K, (4, 512)), ("b.weight", Q.Q8_0, (3, 96)), ("c.bias", Q.F32, (7,)), ("d.weight", Q.Q6_K, (1, 256)),
+            ("e.scale", Q.F16, (5,)), ("f.weight", Q.IQ4_XS, (2, 2, 256)), ("g.w", Q.BF16, (3, 4))]
+    raw = {}
+    for i, (name, q, shape) in enumerate(spec):
+        if q in (Q.F32, Q.F16, Q.BF16):
+            n = int(np.prod(shape)) * (4 if q == Q.F32 else 2)
+            data = np.random.default_rng(i).integers(0, 256, n, dtype=np.uint8)
+        else:
+            data = synth.make_tensor_bytes(q, shape, seed=i)
+        raw[name] = data
+        w.add_tensor(name, q, tuple(reversed(shape)), data)
+    path = w.write(str(tmp_path / "t.gguf"))
+    with gf.GGUFFile(path) as f:
+        assert f.version == version and f.alignment == alignment and f.data_offset % alignment == 0
+        assert [t.name for t in f.tensors] == [s[0] for s in spec]
+        whole = np.fromfile(path, dtype=np.uint8)
+        for t, (name, q, shape) in zip(f.tensors, spec):
+            assert t.tensor_type == q and t.shape == tuple(reversed(shape)) and t.offset % alignment == 0
+            assert t.nbytes == raw[name].size and t.n_elements == int(np.prod(shape))
+            assert np.array_equal(t.data.numpy(), raw[name])
+            assert np.array_equal(whole[f.data_offset + t.offset: f.data_offset + t.offset + t.nbytes], raw[name])
+        assert f.file_bytes == whole.size == f.data_offset + f.data_bytes
+
+
+def test_type_geometry_table(pkg):
+    import ctypes
+    L, qt = pkg._native.lib(), pkg.qtypes
+    bs, ts = ctypes.c_uint32(), ctypes.c_uint32()
+    for q, geo in qt.GGML_QUANT_SIZES.items():
+        assert L.ggq_ggml_type_geometry(int(q), ctypes.byref(bs), ctypes.byref(ts)) == 0 and (bs.value, ts.value) == geo, q
+    assert L.ggq_ggml_type_geometry(4, ctypes.byref(bs), ctypes.byref(ts)) != 0 and (bs.value, ts.value) == (0, 0)   # removed Q4_2
+
+
+def test_corrupt_and_truncated_files_are_rejected_not_crashed_on(pkg, gf, tmp_path):
+    good = HAND_FILE
+    with pytest.raises(OSError):
+        gf.GGUFFile(str(tmp_path / "missing.gguf"))
+    cases = {
+        "magic": b"GGML" + good[4:],
+        "version1": good[:4] + struct.pack("<I", 1) + good[8:],
+        "bigendian": good[:4] + struct.pack(">I", 3) + good[8:],
+        "huge_kv_count": good[:16] + struct.pack("<Q", 2**60) + good[24:],
+        "huge_tensor_count": good[:8] + struct.pack("<Q", 2**61) + good[16:],
+        "short": good[:20],
+        "empty": b"",
+    }
+    for name, data in cases.items():
+        with pytest.raises(ValueError, match="GGUF"):
+            gf.GGUFFile(_write(tmp_path, data, f"{name}.gguf"))
+    # every truncation point: either a clean parse error or (past the last byte any table needs) success
+    for cut in range(0, len(good)):
+        p = _write(tmp_path, good[:cut], "cut.gguf")
+        try:
+            gf.GGUFFile(p).close()
+            ok = True
+        except ValueError:
+            ok = False
+        assert ok == (cut >= len(good)), cut       # the last tensor's bytes end the file: any cut loses data
+    # single-field corruptions of the tensor table
+    head = bytearray(good)
+    q8 = good.index(b"w.weight") + 8
+    bad_dims = bytes(head[:q8]) + struct.pack("<I", 9) + bytes(head[q8 + 4:])
+    with pytest.raises(ValueError):
+        gf.GGUFFile(_write(tmp_path, bad_dims, "dims.gguf"))
+    off_pos = q8 + 4 + 16 + 4
+    assert struct.unpack_from("<Q", good, off_pos)[0] == 32
+    for bad_off in (16, 64, 2**40):                                       # misaligned / past the end
+        data = good[:off_pos] + struct.pack("<Q", bad_off) + good[off_pos + 8:]
+        with pytest.raises(ValueError):
+            gf.GGUFFile(_write(tmp_path, data, "off.gguf"))
+    bad_row = good[:q8 + 4] + struct.pack("<Q", 33) + good[q8 + 12:]      # Q8_0 row of 33 elements: not whole blocks
+    with pytest.raises(ValueError):
+        gf.GGUFFile(_write(tmp_path, bad_row, "row.gguf"))
+    # random byte flips in the header must never crash the process
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        b = bytearray(good)
+        for pos in rng.integers(0, len(_HAND_HEAD), size=3):
+            b[pos] = rng.integers(0, 256)
+        try:
+            gf.GGUFFile(_write(tmp_path, bytes(b), "fuzz.gguf")).close()
+        except (ValueError, UnicodeDecodeError):
+            pass
+
+
+def _model_file(pkg, tmp_path, arch="flux", prefix="model.diffusion_model.", extra_kv=()):
+    Q, synth = pkg.qtypes.Q, pkg.synth
+    w = GGUFWriter(arch=arch)
+    for kv in extra_kv:
+        w.add(*kv)
+    spec = [(prefix + "double_blocks.0.img_attn.qkv.weight", Q.Q5_K, (24, 256)), (prefix + "double_blocks.0.img_attn.proj.weight", Q.Q4_K, (8, 512)),
+            (prefix + "img_in.bias", Q.F32, (16,)), (prefix + "img_in.weight", Q.F16, (16, 4)), (prefix + "norm.scale", Q.BF16, (6,)),
+            ("other.tensor", Q.Q8_0, (2, 32)), (prefix + "x.conv.weight", Q.Q8_0, (2, 3, 1, 32))]
+    packed = {}
+    for i, (name, q, shape) in enumerate(spec):
+        n = int(np.prod(shape))
+        if q == Q.F32:
+            data = np.arange(n, dtype=np.float32) * 0.5
+        elif q == Q.F16:
+            data = (np.arange(n, dtype=np.float32) - 3).astype(np.float16)
+        elif q == Q.BF16:
+            data = (np.array([1.0, -2.0, 0.5, 3.0, 100.0, -0.125], dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        else:
+            data = synth.make_tensor_bytes(q, shape, seed=40 + i, mode="signed")
+        packed[name] = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        w.add_tensor(name, q, tuple(reversed(shape)), data)
+    return w.write(str(tmp_path / f"{arch}.gguf")), spec, packed
+
+
+def test_gguf_sd_loader_mirrors_the_reference(pkg, tmp_path):
+    import oracle
+    Q, ld = pkg.qtypes.Q, pkg.loader
+    pre = "model.diffusion_model."
+    path, spec, packed = _model_file(pkg, tmp_path, extra_kv=[(f"comfy.gguf.orig_shape.{pre}x.conv.weight", ARRAY, [2, 3, 32], INT32)])
+    sd, arch = ld.gguf_sd_loader(path, return_arch=True)
+    assert arch == "flux"
+    # prefix present -> only prefixed tensors, prefix stripped (loader.py:57-71)
+    assert set(sd) == {n[len(pre):] for n, _, _ in spec if n.startswith(pre)} and "other.tensor" not in sd
+    qkv = sd["double_blocks.0.img_attn.qkv.weight"]
+    assert isinstance(qkv, pkg.ops.GGMLTensor) and qkv.tensor_type == Q.Q5_K and qkv.shape == torch.Size((24, 256))
+    assert qkv.dtype == torch.uint8 and not qkv.is_cuda and np.array_equal(qkv.numpy(), packed[pre + "double_blocks.0.img_attn.qkv.weight"])
+    assert getattr(qkv, "is_largest_weight", False) and not getattr(sd["double_blocks.0.img_attn.proj.weight"], "is_largest_weight", False)
+    # F32 / F16 are viewed to their dtype and logical shape (loader.py:119-120)
+    assert sd["img_in.bias"].dtype == torch.float32 and torch.equal(torch.Tensor(sd["img_in.bias"]), torch.arange(16) * 0.5)
+    assert sd["img_in.weight"].dtype == torch.float16 and tuple(sd["img_in.weight"].size()) == (16, 4)
+    # 1-D BF16 is dequantized to fp32 at load (loader.py:123-125)
+    assert sd["norm.scale"].dtype == torch.float32 and sd["norm.scale"].tolist() == [1.0, -2.0, 0.5, 3.0, 100.0, -0.125]
+    # comfy.gguf.orig_shape.* overrides the reversed ggml dims (loader.py:16-24,108-110)
+    assert sd["x.conv.weight"].shape == torch.Size((2, 3, 32)) and sd["x.conv.weight"].tensor_type == Q.Q8_0
+    # the packed views feed the oracle to the same values the file was built from
+    want = oracle.dequant_f16(Q.Q4_K, packed[pre + "double_blocks.0.img_attn.proj.weight"])
+    assert np.array_equal(oracle.dequant_f16(Q.Q4_K, sd["double_blocks.0.img_attn.proj.weight"].numpy()), want)
+    # no prefix in the file -> every tensor, names untouched; handle_prefix=None likewise
+    path2, spec2, _ = _model_file(pkg, tmp_path, arch="sd3", prefix="")
+    assert set(ld.gguf_sd_loader(path2)) == {n for n, _, _ in spec2}
+    assert set(ld.gguf_sd_loader(path, handle_prefix=None)) == {n for n, _, _ in spec}
+
+
+def test_gguf_sd_loader_architecture_checks(pkg, tmp_path):
+    ld = pkg.loader
+    path_t5, _, _ = _model_file(pkg, tmp_path, arch="t5", prefix="")
+    with pytest.raises(ValueError, match="Unexpected architecture type in GGUF file: 't5'"):
+        ld.gguf_sd_loader(path_t5)
+    assert ld.gguf_sd_loader(path_t5, is_text_model=True, return_arch=True)[1] == "t5"
+    path_flux, _, _ = _model_file(pkg, tmp_path, arch="flux")
+    with pytest.raises(ValueError, match="Unexpected text model architecture"):
+        ld.gguf_sd_loader(path_flux, is_text_model=True)
+    path_vis, _, _ = _model_file(pkg, tmp_path, arch="clip", prefix="", extra_kv=[("general.type", STRING, "mmproj")])
+    assert ld.gguf_sd_loader(path_vis, is_text_model=True, return_arch=True)[1] == "clip"
+    # no architecture key: sd.cpp compatibility mode needs the (control-plane) detector
+    w = GGUFWriter(arch=None)
+    w.add_tensor("a.weight", pkg.qtypes.Q.F32, (4,), np.zeros(4, np.float32))
+    p = w.write(str(tmp_path / "noarch.gguf"))
+    with pytest.raises(ValueError, match="incompatible with llama.cpp"):
+        ld.gguf_sd_loader(p, is_text_model=True)
+    with pytest.raises(ValueError, match="not currently supported"):
+        ld.gguf_sd_loader(p)
+
+    class _Arch:
+        arch = "sdxl"
+    sd, arch = ld.gguf_sd_loader(p, return_arch=True, detect_arch=lambda keys: _Arch())
+    assert arch == "sdxl" and set(sd) == {"a.weight"}
+    w = GGUFWriter(arch="flux")
+    w.add("comfy.gguf.orig_shape.a.weight", ARRAY, [2, 2], INT64)
+    w.add_tensor("a.weight", pkg.qtypes.Q.F32, (4,), np.zeros(4, np.float32))
+    with pytest.raises(TypeError, match="Bad original shape metadata"):
+        ld.gguf_sd_loader(w.write(str(tmp_path / "badshape.gguf")))
+
+
+def test_upload_argument_checks_without_a_gpu(pkg, gf, tmp_path):
+    nat = pkg._native
+    with gf.GGUFFile(_write(tmp_path, HAND_FILE)) as f:
+        L = nat.lib()
+        assert L.ggq_gguf_upload(f._h, None, 0, 0, 0, 0, None) == nat.GGQ_OK                 # nothing to copy
+        assert L.ggq_gguf_upload(f._h, None, 0, 10, 0, 0, None) == nat.GGQ_ERR_ARG           # NULL destination
+        assert L.ggq_gguf_upload(f._h, 4096, 90, 20, 0, 0, None) == nat.GGQ_ERR_ARG          # range past the data section
+        assert L.ggq_gguf_upload(None, 4096, 0, 10, 0, 0, None) == nat.GGQ_ERR_ARG
+        with pytest.raises(ValueError, match="AMD GPU"):
+            f.upload("cpu")
+    assert b"GGUF" in nat.lib().ggq_strerror(nat.GGQ_ERR_FORMAT)

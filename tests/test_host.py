@@ -42,9 +42,12 @@ def test_synth_is_deterministic_and_sanitised(pkg):
 
 
 def _declared_symbols():
-    with open(os.path.join(ROOT, "include", "ggq.h")) as f:
-        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\b(ggq_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("ggq.h", "ggq_gguf.h"):
+        with open(os.path.join(ROOT, "include", header)) as f:
+            text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+        names |= set(re.findall(r"\b(ggq_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(pkg):
