@@ -59,7 +59,7 @@ def hip_supported(qtype):
     return _qtype_key(qtype) in HIP_QTYPES
 
 
-def _as_bytes(data):
+def _as_bytes(data, align=True):
     """dequant.py:37-39: rows = data.reshape((-1, data.shape[-1])).view(torch.uint8), flattened."""
     if type(data) is not torch.Tensor:
         data = data.as_subclass(torch.Tensor)          # strip GGMLTensor: plain byte buffer from here on
@@ -68,7 +68,7 @@ def _as_bytes(data):
     data = data.reshape(-1)
     if not data.is_contiguous():
         data = data.contiguous()
-    if data.data_ptr() % 16:
+    if align and data.data_ptr() % 16:
         data = data.clone()                            # fresh allocations are >= 256-B aligned
     return data
 
@@ -90,6 +90,42 @@ def _check_compute(dtype):
         raise GGQUnsupported(f"dequant_dtype={dtype}: the HIP kernels compute in float16, bfloat16 or float32") from None
 
 
+# ---- torch.compile: the launch as an opaque custom op ------------------------------------------------
+# The reference lets torch >= 2.8 compile straight through its forward (ops.py:20-42).  A ctypes call is
+# not traceable, so while Dynamo is tracing the launch goes through `ggq::dequantize`, a
+# torch.library custom op with a fake (meta) implementation; eager calls keep the direct ctypes path
+# (no dispatcher overhead on the per-layer hot loop).
+_TORCH_OF_CODE = {v: k for k, v in _OUT_CODE.items()}
+
+
+def _dequantize_op_impl(data: torch.Tensor, qtype: int, compute: int, out: int) -> torch.Tensor:
+    block_size, type_size = GGML_QUANT_SIZES[Q(qtype)]
+    n_blocks = data.numel() // type_size
+    res = torch.empty(n_blocks * block_size, dtype=_TORCH_OF_CODE[out], device=data.device)
+    if n_blocks:
+        if not data.is_contiguous() or data.data_ptr() % 16:
+            data = data.contiguous().clone()
+        _launch(qtype, data, n_blocks, res, compute, out)
+    return res
+
+
+def _dequantize_op_fake(data, qtype, compute, out):
+    block_size, type_size = GGML_QUANT_SIZES[Q(qtype)]
+    return data.new_empty((data.numel() // type_size) * block_size, dtype=_TORCH_OF_CODE[out])
+
+
+try:
+    _dequantize_op = torch.library.custom_op("ggq::dequantize", _dequantize_op_impl, mutates_args=(), device_types="cuda")
+    _dequantize_op.register_fake(_dequantize_op_fake)
+except (AttributeError, RuntimeError):       # torch without torch.library.custom_op: eager path only
+    _dequantize_op = None
+
+
+def _is_compiling():
+    c = getattr(torch, "compiler", None)
+    return bool(c and hasattr(c, "is_compiling") and c.is_compiling())
+
+
 def _dequant_hip(data, qtype, out_dtype, compute=None):
     """Packed device bytes -> flat dense tensor of ``out_dtype``: the block function's op sequence in
     the ``compute`` dtype (None = fp16), then one cast to ``out_dtype``, in one kernel."""
@@ -100,6 +136,8 @@ def _dequant_hip(data, qtype, out_dtype, compute=None):
     if not data.is_cuda:
         raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
     block_size, type_size = GGML_QUANT_SIZES[key]
+    if _dequantize_op is not None and _is_compiling():
+        return _dequantize_op(_as_bytes(data, align=False), int(key), compute_code, _OUT_CODE[out_dtype])
     data = _as_bytes(data)
     n_blocks = data.numel() // type_size                  # dequant.py:41
     out = torch.empty(n_blocks * block_size, dtype=out_dtype, device=data.device)

@@ -308,6 +308,27 @@ def test_ggml_linear_forward_is_the_reference_call_chain(pkg):
         assert torch.equal(lin(x), lin(x))
 
 
+def test_torch_compile_traces_through_the_custom_op(pkg):
+    """Under torch.compile (the reference allows full compile on torch >= 2.8, ops.py:20-42) the launch is
+    the opaque custom op ggq::dequantize: one graph, no break, same bits as eager."""
+    dq, Q = pkg.dequant, pkg.qtypes.Q
+    if dq._dequantize_op is None:
+        pytest.skip("torch.library.custom_op not available")
+    blocks = pkg.synth.make_blocks(Q.Q4_K, 64 * 2, seed=31)                  # weight 64 x 512
+    data = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    x = torch.randn(3, 512, device=DEV, dtype=torch.bfloat16)
+
+    def f(data, x):
+        w = dq.dequantize(data, Q.Q4_K, (64, 512)).to(x.dtype)
+        return torch.nn.functional.linear(x, w)
+
+    want = f(data, x)
+    got = torch.compile(f, backend="aot_eager", fullgraph=True)(data, x)
+    assert torch.equal(got, want)
+    assert np.array_equal(_bits16(dq.dequantize(data, Q.Q4_K, (64, 512))), oracle.dequant_f16(Q.Q4_K, blocks).view(np.uint16))
+    torch.library.opcheck(torch.ops.ggq.dequantize.default, (data, int(Q.Q4_K), 0, 1))
+
+
 def test_unsupported_requests_raise(pkg):
     dq, Q = pkg.dequant, pkg.qtypes.Q
     data = torch.zeros(144 * 4, dtype=torch.uint8, device=DEV)

@@ -153,6 +153,19 @@ def test_dispatch_and_error_behaviour_on_cpu(pkg, golden_dir):
     assert np.array_equal(out.numpy().view(np.uint32), g["out_f32"].reshape(-1))
 
 
+def test_custom_op_fake_impl_shapes(pkg):
+    """`ggq::dequantize` (the torch.compile entry): the fake implementation predicts shape and dtype
+    from the packed byte count alone -- checked on meta tensors, no GPU."""
+    dq, Q = pkg.dequant, pkg.qtypes.Q
+    if dq._dequantize_op is None:
+        pytest.skip("torch.library.custom_op not available")
+    for q, nbytes, n_el in ((Q.Q4_K, 144 * 4, 1024), (Q.Q8_0, 34 * 3 + 5, 96), (Q.Q6_K, 0, 0)):
+        for code, dt in ((0, torch.float16), (1, torch.bfloat16), (2, torch.float32)):
+            out = dq._dequantize_op_fake(torch.empty(nbytes, dtype=torch.uint8, device="meta"), int(q), 0, code)
+            assert out.shape == (n_el,) and out.dtype == dt and out.device.type == "meta"
+    assert hasattr(torch.ops.ggq, "dequantize")
+
+
 def test_ggml_tensor_carries_attrs(pkg):
     T, Q = pkg.ops.GGMLTensor, pkg.qtypes.Q
     t = T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256))
