@@ -73,14 +73,35 @@ def _as_bytes(data, align=True):
     return data
 
 
+# The per-layer hot loop calls this once per quantized layer per forward (ops.py:177) and the kernel
+# itself takes a few microseconds, so the host side is kept lean: raw stream / device queries, one
+# ctypes call, no torch-function dispatch on the GGMLTensor subclass (each costs microseconds).
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream       # (device_index) -> hipStream_t as int
+    _cur_device = torch._C._cuda_getDevice
+except AttributeError:                                     # torch built without the GPU runtime bindings
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    def _cur_device():
+        return torch.cuda.current_device()
+
+_NoTorchFunction = torch._C.DisableTorchFunctionSubclass
+_ggq_dequant = None
+
+
 def _launch(qtype, data, n_blocks, out, compute_code, out_code):
-    dev = data.device
-    if torch.cuda.current_device() != dev.index:
-        with torch.cuda.device(dev):
+    """Enqueue on torch's CURRENT stream of data's device: orders after the H2D copy, before F.linear."""
+    global _ggq_dequant
+    if _ggq_dequant is None:
+        _ggq_dequant = _native.lib().ggq_dequant
+    index = data.device.index
+    if _cur_device() != index:
+        with torch.cuda.device(index):
             return _launch(qtype, data, n_blocks, out, compute_code, out_code)
-    stream = torch.cuda.current_stream(dev).cuda_stream   # order after the H2D copy, before F.linear
-    rc = _native.lib().ggq_dequant(int(qtype), data.data_ptr(), n_blocks, out.data_ptr(), compute_code, out_code, stream)
-    _native.check(rc, f"ggq_dequant({Q(int(qtype)).name})")
+    rc = _ggq_dequant(qtype, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, out_code, _raw_stream(index))
+    if rc:
+        _native.check(rc, f"ggq_dequant({Q(int(qtype)).name})")
 
 
 def _check_compute(dtype):
@@ -126,23 +147,42 @@ def _is_compiling():
     return bool(c and hasattr(c, "is_compiling") and c.is_compiling())
 
 
-def _dequant_hip(data, qtype, out_dtype, compute=None):
-    """Packed device bytes -> flat dense tensor of ``out_dtype``: the block function's op sequence in
-    the ``compute`` dtype (None = fp16), then one cast to ``out_dtype``, in one kernel."""
-    key = _qtype_key(qtype)
+# qtype (IntEnum member of this package, of the gguf package, or a plain int: all hash alike) ->
+# (ggml type id, block_size, type_size)
+_HIP_TABLE = {k: (int(k),) + tuple(GGML_QUANT_SIZES[k]) for k in HIP_QTYPES}
+
+
+def _dequant_hip(data, qtype, out_dtype, compute=None, oshape=None):
+    """Packed device bytes -> dense tensor of ``out_dtype``: the block function's op sequence in the
+    ``compute`` dtype (None = fp16), then one cast to ``out_dtype``, in one kernel.  Result is flat, or
+    of ``oshape`` when given (must hold exactly the dequantized elements, as the reference's reshape)."""
+    ent = _HIP_TABLE.get(qtype)
+    if ent is None:
+        key = _qtype_key(qtype)
+        if key not in _HIP_TABLE:
+            raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r}")
+        ent = _HIP_TABLE[key]
+    qid, block_size, type_size = ent
     compute_code = _check_compute(compute)
-    if key not in HIP_QTYPES:
-        raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r}")
-    if not data.is_cuda:
-        raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
-    block_size, type_size = GGML_QUANT_SIZES[key]
+    out_code = _OUT_CODE[out_dtype]
     if _dequantize_op is not None and _is_compiling():
-        return _dequantize_op(_as_bytes(data, align=False), int(key), compute_code, _OUT_CODE[out_dtype])
-    data = _as_bytes(data)
-    n_blocks = data.numel() // type_size                  # dequant.py:41
-    out = torch.empty(n_blocks * block_size, dtype=out_dtype, device=data.device)
-    if n_blocks:
-        _launch(key, data, n_blocks, out, compute_code, _OUT_CODE[out_dtype])
+        res = _dequantize_op(_as_bytes(data, align=False), qid, compute_code, out_code)
+        return res if oshape is None else res.reshape(oshape)
+    with _NoTorchFunction():
+        if not data.is_cuda:
+            raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
+        if data.dtype is not torch.uint8 or not data.is_contiguous() or data.data_ptr() & 15:
+            data = _as_bytes(data)                          # views, other storage dtypes, misaligned starts
+        n_blocks = data.numel() // type_size                # dequant.py:41
+        n = n_blocks * block_size
+        if oshape is None:
+            out = torch.empty(n, dtype=out_dtype, device=data.device)
+        else:
+            out = torch.empty(oshape, dtype=out_dtype, device=data.device)
+            if out.numel() != n:
+                raise RuntimeError(f"shape '{list(oshape)}' is invalid for input of size {n}")   # what .reshape(oshape) raises
+        if n_blocks:
+            _launch(qid, data, n_blocks, out, compute_code, out_code)
     return out
 
 
@@ -157,7 +197,7 @@ def dequantize(data, qtype, oshape, dtype=None):
     if key == Q.BF16:
         return dequantize_blocks_BF16(_as_bytes(data), 1, 2, dtype).reshape(oshape)
     _check_compute(dtype)
-    return _dequant_hip(data, qtype, _COMPUTE_TORCH[dtype], compute=dtype).reshape(oshape)
+    return _dequant_hip(data, qtype, _COMPUTE_TORCH[dtype], compute=dtype, oshape=oshape)
 
 
 def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
@@ -167,14 +207,17 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
 
     if qtype in TORCH_COMPATIBLE_QTYPES:
         return tensor.to(dtype)
-    key = _qtype_key(qtype)
-    if key in HIP_QTYPES:
+    key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
+    if key in _HIP_TABLE:
         dequant_dtype = dtype if dequant_dtype == "target" else dequant_dtype
         _check_compute(dequant_dtype)
+        # the packed bytes are read straight off the GGMLTensor (the reference's `tensor.data`, dequant.py:23;
+        # `.data` on a Tensor subclass is one more torch-function round trip for the same storage)
+        data = tensor if isinstance(tensor, torch.Tensor) else tensor.data
         if dtype in _OUT_CODE:
             # dequantize(..., dtype=dequant_dtype).to(dtype) with the cast fused into the kernel's store
-            return _dequant_hip(tensor.data, key, dtype, compute=dequant_dtype).reshape(oshape)
-        return _dequant_hip(tensor.data, key, _COMPUTE_TORCH[dequant_dtype], compute=dequant_dtype).reshape(oshape).to(dtype)
+            return _dequant_hip(data, key, dtype, compute=dequant_dtype, oshape=oshape)
+        return _dequant_hip(data, key, _COMPUTE_TORCH[dequant_dtype], compute=dequant_dtype, oshape=oshape).to(dtype)
     if key == Q.BF16:
         return dequantize(tensor.data, key, oshape, dtype=dequant_dtype).to(dtype)
     raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r} "

@@ -18,11 +18,6 @@ from . import dequant as _hip
 _installed = {}
 
 
-def _takes_hip(data, qtype, dequant_dtype):
-    return (isinstance(data, torch.Tensor) and data.is_cuda and _hip.hip_supported(qtype)
-            and dequant_dtype in _hip._COMPUTE_CODE)
-
-
 def install(ref_dequant, ref_ops=None, ref_loader=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
@@ -30,18 +25,25 @@ def install(ref_dequant, ref_ops=None, ref_loader=None):
     from . import _native
     _native.lib()                                   # fail now, loudly, if the extension is absent
     orig = {"dequantize": ref_dequant.dequantize, "dequantize_tensor": ref_dequant.dequantize_tensor}
+    unsupported = _hip.GGQUnsupported
+    hip_dequantize, hip_dequantize_tensor = _hip.dequantize, _hip.dequantize_tensor
+    orig_dequantize, orig_dequantize_tensor = orig["dequantize"], orig["dequantize_tensor"]
 
+    # Try the HIP path first; a request it does not serve (CPU-resident bytes at load time, a qtype
+    # without a kernel, an exotic dequant_dtype) raises GGQUnsupported BEFORE anything is launched and
+    # is handed to the reference's own function.  No eligibility pre-checks: on the per-layer hot loop
+    # every attribute probe of a Tensor subclass costs about as much as the kernel launch itself.
     def dequantize(data, qtype, oshape, dtype=None):
-        if _takes_hip(data, qtype, dtype):
-            return _hip.dequantize(data, qtype, oshape, dtype=dtype)
-        return orig["dequantize"](data, qtype, oshape, dtype=dtype)
+        try:
+            return hip_dequantize(data, qtype, oshape, dtype=dtype)
+        except unsupported:
+            return orig_dequantize(data, qtype, oshape, dtype=dtype)
 
     def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
-        qtype = getattr(tensor, "tensor_type", None)
-        resolved = dtype if dequant_dtype == "target" else dequant_dtype
-        if qtype not in ref_dequant.TORCH_COMPATIBLE_QTYPES and _takes_hip(tensor, qtype, resolved):
-            return _hip.dequantize_tensor(tensor, dtype, dequant_dtype)
-        return orig["dequantize_tensor"](tensor, dtype, dequant_dtype)
+        try:
+            return hip_dequantize_tensor(tensor, dtype, dequant_dtype)
+        except unsupported:
+            return orig_dequantize_tensor(tensor, dtype, dequant_dtype)
 
     dequantize.__wrapped__ = orig["dequantize"]
     dequantize_tensor.__wrapped__ = orig["dequantize_tensor"]
