@@ -618,6 +618,27 @@ static void pmc_sequence()
         for (int i = 0; i < 5; i++) ggq_plan_launch(plan, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
         ggq_plan_destroy(plan);
+        if (QTS[qi].id == 12) {
+            // the other (compute dtype -> out dtype) modes of the headline format on the same packed pool
+            uint8_t* out32 = nullptr;
+            HIP_CHECK(hipMalloc(&out32, P.elements * 4));
+            const int modes[][2] = {{GGQ_F16, GGQ_BF16}, {GGQ_BF16, GGQ_BF16}, {GGQ_F32, GGQ_F32}, {GGQ_F16, GGQ_F32}};
+            for (const auto& m : modes) {
+                std::vector<ggq_desc> dm;
+                uint64_t oo = 0;
+                for (auto& d : P.descs) {
+                    dm.push_back(ggq_desc{QTS[qi].id, m[1], d.packed, out32 + oo, d.n_blocks, m[0], 0});
+                    oo += d.n_blocks * P.bs * (m[1] == GGQ_F32 ? 4 : 2);
+                }
+                ggq_plan* pm = nullptr;
+                if (ggq_plan_create(dm.data(), (uint32_t)dm.size(), &pm)) { printf("plan_create failed\n"); continue; }
+                printf("PMC %s compute=%d out=%d: %llu B per launch\n", QTS[qi].name, m[0], m[1], (unsigned long long)ggq_plan_bytes(pm));
+                for (int i = 0; i < 5; i++) ggq_plan_launch(pm, nullptr);
+                HIP_CHECK(hipDeviceSynchronize());
+                ggq_plan_destroy(pm);
+            }
+            HIP_CHECK(hipFree(out32));
+        }
         free_pool(P);
     }
 }

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes of tests/microbench/pmc.sh (gpurun_out/pmc/p{1,2,3}) into the
+table committed under profiles/: HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate passes),
+corrected as MI355X_MICROARCH.md prescribes and calibrated on the known-size streams of the same pass.
+
+    python tools/pmc_summarize.py gpurun_out/pmc > profiles/<name>.txt
+"""
+import collections
+import csv
+import re
+import sys
+
+
+def counters(path, name):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+
+def durations(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+
+TS = {"FmtQ4_K": 144 / 256, "FmtQ4_0": 18 / 32, "FmtQ6_K": 210 / 256, "FmtQ8_0": 34 / 32, "FmtQ5_0": 22 / 32}
+ELEMENTS = 64 * (3072 * 3072 + 3072 * 12288)
+DT = {"0": "f16", "1": "bf16", "2": "f32"}
+
+
+def main(root):
+    fetch = counters(f"{root}/p1/p_counter_collection.csv", "FETCH_SIZE")
+    write = counters(f"{root}/p2/p_counter_collection.csv", "WRITE_SIZE")
+    dur = durations(f"{root}/p1/p_kernel_trace.csv")
+    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), MI355X; bash tests/microbench/pmc.sh")
+    print("# pools: 64 x (3072x3072 + 3072x12288) per format, shipped kernels via ggq_plan_launch; counter = mean over the launches of that kernel")
+    print("# correction: read bytes = FETCH_SIZE * 2048 (gfx950 counts 16 B/lane streams at half rate; calibrated below on 1 GiB copies), write bytes = WRITE_SIZE * 1024")
+    print(f"{'kernel (compute->out)':28s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s} {'read B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'write B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'avg us':>9s}")
+    for k in fetch:
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)>", k)
+        if m:
+            fmt, out, comp = m.groups()
+            name = f"{fmt} {DT[comp]}->{DT[out]}"
+            a_read = ELEMENTS * TS[fmt]
+            a_write = ELEMENTS * (4 if out == "2" else 2)
+        elif k.startswith(("k_copy16", "k_fill16")):
+            name = k.split("(")[0]
+            a_read = (1 << 30) if "copy" in name else 0
+            a_write = 1 << 30
+        else:
+            continue
+        rb, wb = fetch[k] * 2048, write.get(k, 0.0) * 1024
+        rr = f"{rb / a_read:7.4f}" if a_read else "    nan"
+        print(f"{name:28s} {fetch[k]:12.1f} {write.get(k, 0.0):12.1f} {rb:14.0f} {a_read:14.0f} {rr} {wb:14.0f} {a_write:14.0f} {wb / a_write:7.4f} {dur.get(k, 0.0):9.1f}")
+    sq = f"{root}/p3/p_counter_collection.csv"
+    names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+             "SQ_LDS_UNALIGNED_STALL", "GRBM_GUI_ACTIVE"]
+    try:
+        cols = {n: counters(sq, n) for n in names}
+    except OSError:
+        return
+    print("\n# SQ pass (per launch; SQ_* cycle counters are quad-cycles summed over waves)")
+    print(f"{'kernel (compute->out)':28s} " + " ".join(f"{n:>22s}" for n in names))
+    for k in cols["SQ_WAVES"]:
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)>", k)
+        if not m:
+            continue
+        fmt, out, comp = m.groups()
+        print(f"{fmt + ' ' + DT[comp] + '->' + DT[out]:28s} " + " ".join(f"{cols[n].get(k, float('nan')):22.4g}" for n in names))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
