@@ -394,14 +394,39 @@ GGQ_DEV u32x2 quad_f16(const Fields& f, uint32_t t)
 
 // fp32 / bf16 arithmetic share one body: values live in fp32 registers; RB = true rounds every
 // result to bf16 (RNE) -- exactly what torch's bf16 kernels do (fp32 op, then round).  Integers
-// (|q| <= 255) are exact in both dtypes.
+// (|q| <= 255) are exact in both dtypes.  Roundings go through the hardware converter two at a time:
+// v_cvt_pk_bf16_f32 packs (a, b) as bf16, and a bf16 is the top half of its fp32 value.
 typedef __bf16 bf16_t;
+typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+GGQ_DEV uint32_t pack_bf16(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2)); }
+GGQ_DEV float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+
 template <bool RB> GGQ_DEV float rnd(float x)
 {
-    if constexpr (RB) return (float)(bf16_t)x;      // gfx950: v_cvt_pk_bf16_f32, then << 16
+    if constexpr (RB) return (float)(bf16_t)x;
     else return x;
 }
+template <bool RB> GGQ_DEV void rnd2(float& a, float& b)
+{
+    if constexpr (RB) {
+        const uint32_t p = pack_bf16(a, b);
+        a = bits_f32(p << 16);
+        b = bits_f32(p & 0xFFFF0000u);
+    }
+}
 
+template <bool RB> GGQ_DEV f32x4 rnd4(f32x4 v)
+{
+    float a = v.x, b = v.y, c = v.z, d = v.w;
+    rnd2<RB>(a, b);
+    rnd2<RB>(c, d);
+    return f32x4{a, b, c, d};
+}
+
+// Returns the results of the LAST op of the sequence, not yet rounded to bf16 when RB: the output
+// stage applies that final rounding together with the `.to(dtype)` conversion (for a bf16 result the
+// two coincide in one v_cvt_pk_bf16_f32).
 template <int KIND, int BIAS, bool RB>
 GGQ_DEV f32x4 quad_f32(const Fields& f, uint32_t t)
 {
@@ -411,20 +436,28 @@ GGQ_DEV f32x4 quad_f32(const Fields& f, uint32_t t)
     const float d = rnd<RB>((float)h_of(f.dm));
     if constexpr (KIND == K_D) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(d * q[i]);
+        for (int i = 0; i < 4; i++) r[i] = d * q[i];
     } else if constexpr (KIND == K_DM) {
         const float m = rnd<RB>((float)h_of(f.dm >> 16));
 #pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(rnd<RB>(d * q[i]) + m);
-    } else if constexpr (KIND == K_SCMN) {
-        const float dmin = rnd<RB>((float)h_of(f.dm >> 16));
-        const float dl = rnd<RB>(d * (float)f.sc), ml = rnd<RB>(dmin * (float)f.mn);
+        for (int i = 0; i < 4; i++) r[i] = d * q[i];
+        rnd2<RB>(r[0], r[1]);
+        rnd2<RB>(r[2], r[3]);
 #pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(rnd<RB>(dl * q[i]) - ml);
+        for (int i = 0; i < 4; i++) r[i] = r[i] + m;
+    } else if constexpr (KIND == K_SCMN) {
+        float dl = d * (float)f.sc, ml = rnd<RB>((float)h_of(f.dm >> 16)) * (float)f.mn;
+        rnd2<RB>(dl, ml);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = dl * q[i];
+        rnd2<RB>(r[0], r[1]);
+        rnd2<RB>(r[2], r[3]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = r[i] - ml;
     } else {
         const float dl = rnd<RB>(d * (float)f.sc);
 #pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = rnd<RB>(dl * q[i]);
+        for (int i = 0; i < 4; i++) r[i] = dl * q[i];
     }
     return f32x4{r[0], r[1], r[2], r[3]};
 }
@@ -461,9 +494,6 @@ GGQ_DEV u32x4 gload16(gcptr p)
 
 // The final `.to(dtype)` (dequant.py:23) is one RNE conversion, done in registers by the hardware
 // converters (v_cvt_f32_f16 is exact; v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 round to nearest even).
-typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
-typedef float f2 __attribute__((ext_vector_type(2)));
-GGQ_DEV uint32_t pack_bf16(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2)); }
 GGQ_DEV uint32_t pack_f16(float a, float b) { return as_u32(h2{(_Float16)a, (_Float16)b}); }
 GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh) { const h2 v = as_h2(hh); return pack_bf16((float)v.x, (float)v.y); }
 
@@ -487,14 +517,19 @@ GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
             const h2 a = as_h2(v.x), b = as_h2(v.y);
             gstore<NT>(out + elem * 4, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
         } else {
-            gstore<NT>(out + elem * 4, quad_f32<KIND, BIAS, RB>(f, t));
+            gstore<NT>(out + elem * 4, rnd4<RB>(quad_f32<KIND, BIAS, RB>(f, t)));
         }
     } else if constexpr (ARITH == AR_F16) {
         const u32x2 lo = quad_f16<KIND, BIAS>(f, f.t0), hi = quad_f16<KIND, BIAS>(f, f.t1);
         if constexpr (OUT == OUT_F16) gstore<NT>(out + elem * 2, u32x4{lo.x, lo.y, hi.x, hi.y});
         else gstore<NT>(out + elem * 2, u32x4{h2_to_bf16x2(lo.x), h2_to_bf16x2(lo.y), h2_to_bf16x2(hi.x), h2_to_bf16x2(hi.y)});
     } else {
-        const f32x4 lo = quad_f32<KIND, BIAS, RB>(f, f.t0), hi = quad_f32<KIND, BIAS, RB>(f, f.t1);
+        f32x4 lo = quad_f32<KIND, BIAS, RB>(f, f.t0), hi = quad_f32<KIND, BIAS, RB>(f, f.t1);
+        if constexpr (OUT == OUT_F16) {          // bf16 arithmetic, fp16 result: round to bf16 FIRST, then to fp16
+            lo = rnd4<RB>(lo);
+            hi = rnd4<RB>(hi);
+        }
+        // bf16 result: RNE of the fp32 op result == the op's own bf16 rounding (RB) or the cast of an fp32 value
         if constexpr (OUT == OUT_BF16) gstore<NT>(out + elem * 2, u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)});
         else gstore<NT>(out + elem * 2, u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)});
     }
