@@ -22,8 +22,8 @@ _lib = None
 
 def build(force=False):
     """Compile ggq_oracle.c with gcc (seconds)."""
-    src = os.path.join(_HERE, "ggq_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ggq_oracle.c", "ggq_oracle_simd.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
                        stdout=subprocess.DEVNULL if not force else None)
     return _SO
@@ -35,7 +35,8 @@ def lib():
         build()
         L = ctypes.CDLL(_SO)
         u8p, u16p, f32p, u32p = (ctypes.POINTER(t) for t in (ctypes.c_uint8, ctypes.c_uint16, ctypes.c_float, ctypes.c_uint32))
-        for name, outp in (("ggq_oracle_dequant_f16", u16p), ("ggq_oracle_dequant_f32", f32p), ("ggq_oracle_dequant_bf16", u16p)):
+        for name, outp in (("ggq_oracle_dequant_f16", u16p), ("ggq_oracle_dequant_f32", f32p), ("ggq_oracle_dequant_bf16", u16p),
+                           ("ggq_oracle_simd_dequant_f16", u16p)):
             fn = getattr(L, name)
             fn.argtypes = [ctypes.c_int, u8p, ctypes.c_uint64, outp]
             fn.restype = ctypes.c_int
@@ -77,14 +78,25 @@ def _prep(qtype, packed):
     return packed, n_blocks, bs
 
 
-def dequant_f16(qtype, packed, threads=None):
-    """Default path (dequant_dtype=None): returns the fp16 result as a 1-D np.float16 array."""
+def simd_available():
+    """True if the host can run the AVX2+F16C throughput leg (ggq_oracle_simd.c)."""
+    return bool(lib().ggq_oracle_simd_available())
+
+
+def dequant_f16(qtype, packed, threads=None, simd=False, out=None):
+    """Default path (dequant_dtype=None): returns the fp16 result as a 1-D np.float16 array.
+    simd=True runs the AVX2+F16C leg (same values; bench.py's cpu_baseline) instead of the soft-float checker;
+    ``out`` (np.uint16, right size) avoids re-allocating the result when timing."""
     L = lib()
     if threads:
         L.ggq_oracle_set_threads(int(threads))
     packed, n_blocks, bs = _prep(qtype, packed)
-    out = np.empty(n_blocks * bs, dtype=np.uint16)
-    rc = L.ggq_oracle_dequant_f16(int(qtype), _ptr(packed, ctypes.c_uint8), n_blocks, _ptr(out, ctypes.c_uint16))
+    if out is None:
+        out = np.empty(n_blocks * bs, dtype=np.uint16)
+    fn = L.ggq_oracle_simd_dequant_f16 if simd else L.ggq_oracle_dequant_f16
+    rc = fn(int(qtype), _ptr(packed, ctypes.c_uint8), n_blocks, _ptr(out, ctypes.c_uint16))
+    if rc == -2:
+        raise RuntimeError("oracle: this host has no AVX2+F16C")
     if rc:
         raise ValueError(f"oracle: unsupported qtype {int(qtype)}")
     return out.view(np.float16)

@@ -125,3 +125,24 @@ def test_oracle_matches_live_reference(pkg, name, mode):
     blocks = pkg.synth.make_blocks(q, 96, seed=4242, mode=mode)
     want = ref.dequantize(torch.from_numpy(blocks.reshape(-1).copy()), q, (96 * bs,)).numpy()
     assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
+
+
+@pytest.mark.parametrize("mode", ["nominal", "signed", "adversarial", "raw"])
+def test_simd_throughput_leg_equals_the_soft_float_checker(pkg, golden_dir, mode):
+    """oracle/ggq_oracle_simd.c (bench.py's cpu_baseline leg) == oracle/ggq_oracle.c, bit for bit, and hence
+    == the reference's golden vectors."""
+    if not oracle.simd_available():
+        pytest.skip("host has no AVX2+F16C")
+    for q in pkg.qtypes.HIP_QTYPES:
+        bs, _ = pkg.qtypes.block_geometry(q)
+        blocks = pkg.synth.make_blocks(q, 4099 if bs == 32 else 515, seed=77, mode=mode)
+        soft = oracle.dequant_f16(q, blocks)
+        for threads in (1, 3):
+            fast = oracle.dequant_f16(q, blocks, threads=threads, simd=True)
+            assert np.array_equal(oracle.canon_nan_f16(fast), oracle.canon_nan_f16(soft)), (q.name, mode, threads)
+        g = np.load(os.path.join(golden_dir, f"{q.name}.npz"))
+        fast = oracle.dequant_f16(q, g["blocks"], simd=True)
+        assert np.array_equal(oracle.canon_nan_f16(fast), oracle.canon_nan_f16(g["out_f16"].reshape(-1))), q.name
+    assert oracle.dequant_f16(pkg.qtypes.Q.Q4_K, np.zeros(0, np.uint8), simd=True).size == 0
+    with pytest.raises(ValueError):
+        oracle.dequant_f16(99, np.zeros(144, np.uint8), simd=True)
