@@ -24,7 +24,8 @@ Other workloads (not the driver's default; same JSON contract, one line):
   --workload flux        BASELINE configs[3]: the full FLUX.1-dev weight set (304 quantized tensors, Q4_K_M mix:
                          Q4_K + Q5_K), HBM-resident, one mixed-format plan launch per step; with --gpus N the
                          tensor list is SHARDED (strong scaling), no collectives.
-  --workload flux-gguf   the same weight set written to a synthetic .gguf file, then parsed by the native
+  --workload sd35-t5     BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors (549 tensors), same treatment.
+  --workload flux-gguf   the FLUX weight set written to a synthetic .gguf file, then parsed by the native
                          reader, streamed file -> pinned -> HBM and dequantized: the PCIe-inclusive rate.
 
 Prints ONE JSON line on rank 0.
@@ -158,7 +159,10 @@ def cpu_baseline(pkg, plan, qtype, budget_s):
 
 def run_flux(pkg, args, rank, world, device, fence):
     """configs[3]: full FLUX.1-dev weight set, mixed quant types, resident in HBM, sharded over ranks."""
-    manifest = pkg.manifests.flux_dev(args.mix)
+    if args.workload == "sd35-t5":
+        manifest, label = pkg.manifests.sd35_t5(args.mix), "BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors"
+    else:
+        manifest, label = pkg.manifests.flux_dev(args.mix), "BASELINE configs[3]: full FLUX.1-dev weight set"
     mine = pkg.sharding.shard(manifest, rank, world)
     plan = build_pool(pkg, mine, device, seed0=7000 + 1000 * rank)
     gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup, device, fence)
@@ -176,14 +180,14 @@ def run_flux(pkg, args, rank, world, device, fence):
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[3]: full FLUX.1-dev weight set ({len(manifest)} tensors, {args.mix} mix {qcount}), "
+            "config": {"workload": f"{label} ({len(manifest)} tensors, {args.mix} mix {qcount}), "
                                    f"HBM-resident, tensor list sharded over {world} GPU(s)",
                        "elements": sum(s[0] * s[1] for _, _, s in manifest), "bytes_per_step": total_bytes,
                        "kernels_per_step_rank0": plan.kernels, "imbalance": round(pkg.sharding.imbalance(manifest, world), 4),
                        "parallelism": f"tensor-list sharding x{world}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ggq::dequant_many<FmtQ4_K/FmtQ5_K, ...> (one launch per format)",
+                         "kernel": "ggq::dequant_many<Fmt*, ...> (one launch per format present)",
                          "algorithmic_bytes_per_launch": plan.bytes, "avg_launch_ms": round(gpu_ms / args.steps, 5),
                          "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
             "cpu_baseline": None,
@@ -289,7 +293,7 @@ def main():
     ap.add_argument("--no-per-qtype", action="store_true", help="skip the per-format table")
     ap.add_argument("--no-per-mode", action="store_true", help="skip the (dequant_dtype, dtype) table of the headline format")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "flux-gguf"], help="see the module docstring")
+    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
     ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf: only the first N tensors (smoke runs)")
@@ -328,7 +332,7 @@ def main():
     head_q = qt.Q[args.qtype]
 
     if args.workload != "pool":
-        if args.workload == "flux":
+        if args.workload in ("flux", "sd35-t5"):
             result = run_flux(pkg, args, rank, world, device, fence)
         else:
             if world != 1:

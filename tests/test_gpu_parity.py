@@ -308,6 +308,60 @@ def test_ggml_linear_forward_is_the_reference_call_chain(pkg):
         assert torch.equal(lin(x), lin(x))
 
 
+@pytest.mark.parametrize("name,out", [("Q4_K", "f16"), ("Q8_0", "f32"), ("Q6_K", "bf16")])
+def test_outputs_beyond_4_gib(pkg, name, out):
+    """Maximum sizes: a dense result larger than 2^32 bytes (and packed offsets beyond 2^31) -- every
+    address computation must be 64-bit.  Windows around the 2^31 / 2^32 byte marks of the output, the head,
+    the ragged tail and random places are checked against the oracle."""
+    q = pkg.qtypes.Q[name]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    itemsize = 4 if out == "f32" else 2
+    n_el = (1 << 32) // itemsize + 2048 * 37 + bs * 3                        # > 4 GiB of output, ragged last group
+    n_blocks = n_el // bs
+    g = torch.Generator(device=DEV)
+    g.manual_seed(123)
+    data = torch.randint(0, 256, (n_blocks * ts,), dtype=torch.uint8, device=DEV, generator=g)
+    t = pkg.ops.GGMLTensor(data, tensor_type=q, tensor_shape=(n_blocks, bs))
+    got = pkg.dequant.dequantize_tensor(t, _TORCH[out])
+    assert got.numel() == n_blocks * bs and got.numel() * itemsize > (1 << 32)
+    win = 192 if bs == 32 else 24                                            # blocks per window (3 groups)
+    marks = [0, n_blocks - win, (1 << 31) // itemsize // bs - win // 2, (1 << 32) // itemsize // bs - win // 2,
+             (1 << 30) // ts - win // 2, (1 << 31) // ts - win // 2]
+    rng = np.random.default_rng(5)
+    marks += [int(x) for x in rng.integers(0, n_blocks - win, size=6)]
+    for b0 in marks:
+        b0 = max(0, min(int(b0), n_blocks - win))
+        packed = data[b0 * ts:(b0 + win) * ts].cpu().numpy()
+        want = oracle.dequant_tensor(q, packed, "f16", out)
+        piece = got.reshape(-1)[b0 * bs:(b0 + win) * bs]
+        assert np.array_equal(_canon(_raw(piece), out), _canon(want, out)), (name, out, b0)
+    del got, data
+    torch.cuda.empty_cache()
+
+
+def test_capturable_in_a_hip_graph(pkg):
+    """The launch only enqueues on torch's current stream and never synchronises, so dequant + F.linear can be
+    captured once (torch.cuda.graph -> hipGraph) and replayed -- the launch-bound per-layer loop as one graph."""
+    Q = pkg.qtypes.Q
+    layers = []
+    for i, q in enumerate((Q.Q4_K, Q.Q8_0, Q.Q6_K, Q.Q5_0)):
+        blocks = pkg.synth.make_blocks(q, 64 * 512 // pkg.qtypes.block_geometry(q)[0], seed=60 + i)
+        layers.append((pkg.ops.GGMLLinear(_carrier(pkg, blocks, q, (64, 512))), q, blocks))
+    x = torch.randn(8, 512, device=DEV, dtype=torch.float16)
+    for lin, _, _ in layers:                                                 # warm-up outside the capture
+        lin(x)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ys = [lin(x) for lin, _, _ in layers]
+    x.copy_(torch.randn(8, 512, device=DEV, dtype=torch.float16))            # new input, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    for y, (lin, q, blocks) in zip(ys, layers):
+        w = torch.from_numpy(oracle.dequant_f16(q, blocks).reshape(64, 512).copy()).to(DEV)
+        assert torch.equal(y, torch.nn.functional.linear(x, w)), q
+
+
 def test_torch_compile_traces_through_the_custom_op(pkg):
     """Under torch.compile (the reference allows full compile on torch >= 2.8, ops.py:20-42) the launch is
     the opaque custom op ggq::dequantize: one graph, no break, same bits as eager."""
