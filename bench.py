@@ -106,6 +106,20 @@ def timed_steps(plan, steps, warmup, device, fence):
     return start.elapsed_time(stop), wall_ms
 
 
+def per_launch_stats(plan, reps, device):
+    """Median / min duration of single launches (one HIP-event pair per launch, same stream) -- the
+    distribution behind the average the timed region reports (median and min)."""
+    stream = torch.cuda.current_stream(device)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    evs[0].record(stream)
+    for i in range(reps):
+        plan.launch(stream)
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize(device)
+    ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(reps))
+    return ms[len(ms) // 2], ms[0]
+
+
 def cpu_baseline(pkg, plan, qtype, budget_s):
     """The CPU leg, timed on this box's host cores on a bounded sample of the same workload: the first
     tensors of the pool (same packed bytes, copied back from the GPU), repeated for ~budget_s seconds.
@@ -362,6 +376,8 @@ def main():
         n_el = sum(s[0] * s[1] for _, _, s in mine)
         wl = f"BASELINE configs[2] {head_q.name}: FLUX.1-dev linear shapes, {args.pairs} x (3072x3072 + 3072x12288) per GPU"
         traffic = load_traffic(f"{head_q.name}:pairs{args.pairs}")
+        med_ms, min_ms = per_launch_stats(plan, max(20, args.steps), device)
+        in_bytes = sum(t.numel() for t in plan._keep)
         result = {
             "metric": "dequant GB/s (packed in -> fp16 out), (in+out) bytes / time",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -369,11 +385,16 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": wl, "qtype": head_q.name, "elements_per_gpu": n_el, "bytes_per_step_per_gpu": bytes_rank,
                        "tensors_per_gpu": len(mine), "parallelism": f"tensor-list sharding x{world}, no collectives",
-                       "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2)},
+                       "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2),
+                       # the three rates of SURVEY.md section 8d, per GPU (rank 0): packed in / dense out / both, over the same time
+                       "rates_GBps": {"in": round(in_bytes / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
+                                      "out": round((bytes_rank - in_bytes) / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
+                                      "in_plus_out": round(achieved, 1)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": f"ggq::dequant_many<Fmt{head_q.name}, ...>", "algorithmic_bytes_per_launch": bytes_rank,
-                         "avg_launch_ms": round(gpu_ms / args.steps, 5), "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
+                         "avg_launch_ms": round(gpu_ms / args.steps, 5), "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
+                         "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
         }
     plan_head = plan
 
