@@ -1,13 +1,14 @@
-"""The input side of the dequant path: GGUF file -> state dict of ``GGMLTensor`` (reference loader.py:16-141),
-without the third-party ``gguf`` package, plus what the reference cannot do: stream the packed weights
-straight into HBM in one pass (``device=...``) so the dequant kernels find them resident.
+"""The input side of the dequant path: GGUF file -> state dict of ``GGMLTensor`` without the third-party
+``gguf`` package, plus what the reference cannot do: stream the packed weights straight into HBM in one
+pass (``device=...``) so the dequant kernels find them resident.
 
-Mirrored surface (same names, argument meaning, results and errors):
+Interface mirrored from the reference (same names, argument meaning, results, error types and messages):
     get_orig_shape(reader, tensor_name)                     loader.py:16-24
     get_field(reader, field_name, field_type)               loader.py:26-37
     get_list_field(reader, field_name, field_type)          loader.py:39-49
     gguf_sd_loader(path, handle_prefix, return_arch, is_text_model)     loader.py:51-141
-``reader`` is a :class:`gguf_file.GGUFFile` instead of a ``gguf.GGUFReader``.
+``reader`` is a :class:`gguf_file.GGUFFile` (native parser) instead of a ``gguf.GGUFReader``; a field is
+``(types, value)`` with the value already decoded, where gguf-py hands out ``parts`` / ``data`` indices.
 
 Not mirrored (the reference's control plane, SURVEY.md section 2 -- left to the reference's own code,
 which keeps working on top of this module's state dicts): key remapping for text encoders, tokenizer
@@ -23,143 +24,148 @@ from .gguf_file import ARRAY, INT32, STRING, GGUFFile
 from .ops import GGMLTensor
 from .qtypes import GGMLQuantizationType as Q
 
+# architectures the loaders accept (loader.py:12-14)
 IMG_ARCH_LIST = {"flux", "sd1", "sdxl", "sd3", "aura", "hidream", "cosmos", "ltxv", "hyvid", "wan", "lumina2", "qwen_image"}
 TXT_ARCH_LIST = {"t5", "t5encoder", "llama", "qwen2vl", "qwen3", "qwen3vl"}
 VIS_TYPE_LIST = {"clip-vision", "mmproj"}
 
+_SCALAR_TYPES = (int, float, bool)
+_PLAIN_DTYPES = {Q.F32: torch.float32, Q.F16: torch.float16}      # stored as-is: viewed, never dequantized
+
+
+# ---- metadata accessors ------------------------------------------------------------------------------
 
 def get_orig_shape(reader, tensor_name):
-    field_key = f"comfy.gguf.orig_shape.{tensor_name}"
-    field = reader.get_field(field_key)
+    """The converter records the torch shape of reshaped tensors under ``comfy.gguf.orig_shape.<name>``
+    (tools/convert.py:293-295); None when the file has no such entry."""
+    key = "comfy.gguf.orig_shape." + tensor_name
+    field = reader.get_field(key)
     if field is None:
         return None
     if field.types != [ARRAY, INT32]:
-        raise TypeError(f"Bad original shape metadata for {field_key}: Expected ARRAY of INT32, got {field.types}")
-    return torch.Size(tuple(int(v) for v in field.value))
+        raise TypeError(f"Bad original shape metadata for {key}: Expected ARRAY of INT32, got {field.types}")
+    return torch.Size(int(dim) for dim in field.value)
+
+
+def _values(field):
+    return field.value if isinstance(field.value, tuple) else (field.value,)
 
 
 def get_field(reader, field_name, field_type):
+    """One metadata value as ``field_type`` (str / int / float / bool); None if the key is absent.  Strings
+    are type-checked (this accessor reads the architecture string); of an array the LAST element counts."""
+    if field_type is not str and field_type not in _SCALAR_TYPES:
+        if reader.get_field(field_name) is None:
+            return None
+        raise TypeError(f"Unknown field type {field_type}")
     field = reader.get_field(field_name)
     if field is None:
         return None
-    elif field_type == str:
+    if field_type is str:
         if field.types != [STRING]:
             raise TypeError(f"Bad type for GGUF {field_name} key: expected string, got {field.types!r}")
         return field.value
-    elif field_type in [int, float, bool]:
-        value = field.value
-        return field_type(value[-1] if isinstance(value, tuple) else value)
-    else:
-        raise TypeError(f"Unknown field type {field_type}")
+    return field_type(_values(field)[-1])
 
 
 def get_list_field(reader, field_name, field_type):
+    """Every element of an array-valued key as a tuple of ``field_type``; None if the key is absent."""
     field = reader.get_field(field_name)
     if field is None:
         return None
-    value = field.value if isinstance(field.value, tuple) else (field.value,)
-    if field_type == str:
-        return tuple(str(v) for v in value)
-    elif field_type in [int, float, bool]:
-        return tuple(field_type(v) for v in value)
-    else:
+    if field_type is not str and field_type not in _SCALAR_TYPES:
         raise TypeError(f"Unknown field type {field_type}")
+    return tuple(field_type(v) for v in _values(field))
+
+
+# ---- the state-dict loader -----------------------------------------------------------------------------
+
+def _select(reader, handle_prefix):
+    """(state-dict key, tensor) pairs.  If ANY tensor name carries ``handle_prefix``, only those are kept and
+    the prefix is stripped; otherwise every tensor is kept under its own name (loader.py:57-71)."""
+    named = [(t.name, t) for t in reader.tensors]
+    if handle_prefix is None or not any(name.startswith(handle_prefix) for name, _ in named):
+        return named
+    cut = len(handle_prefix)
+    return [(name[cut:], t) for name, t in named if name.startswith(handle_prefix)]
+
+
+def _architecture(reader, path, keys, is_text_model, detect_arch):
+    """-> (arch, compat).  Files without architecture metadata (stable-diffusion.cpp exports; the "pig" / "cow"
+    placeholders) are image models loaded in compatibility mode, which needs the reference's key-based detector;
+    a known architecture must match the kind of model being loaded (loader.py:73-92)."""
+    arch = get_field(reader, "general.architecture", str)
+    kind = get_field(reader, "general.type", str)
+    if arch is None or arch in ("pig", "cow"):
+        if is_text_model:
+            raise ValueError(f"This gguf file is incompatible with llama.cpp!\nConsider using safetensors or a compatible gguf file\n({path})")
+        compat = arch or "sd.cpp"
+        try:
+            if detect_arch is None:
+                raise NotImplementedError("no architecture metadata and no detect_arch callable supplied")
+            arch = detect_arch(set(keys)).arch
+        except Exception as e:
+            raise ValueError(f"This model is not currently supported - ({e})")
+        return arch, compat
+    if is_text_model:
+        if arch not in TXT_ARCH_LIST and kind not in VIS_TYPE_LIST:
+            raise ValueError(f"Unexpected text model architecture type in GGUF file: {arch!r}")
+    elif arch not in IMG_ARCH_LIST:
+        raise ValueError(f"Unexpected architecture type in GGUF file: {arch!r}")
+    return arch, None
+
+
+def _logical_shape(reader, tensor, arch, compat):
+    """torch shape of a tensor: the recorded original shape if any, else the ggml dims reversed (ggml lists the
+    fastest dimension first).  stable-diffusion.cpp SDXL exports keep 1x1 conv projections 4-D: trailing unit
+    dims beyond two are dropped there (loader.py:108-116)."""
+    shape = get_orig_shape(reader, tensor.name)
+    if shape is not None:
+        return shape
+    dims = [int(d) for d in reversed(tensor.shape)]
+    if compat == "sd.cpp" and arch == "sdxl" and tensor.name.endswith((".proj_in.weight", ".proj_out.weight")):
+        while len(dims) > 2 and dims[-1] == 1:
+            dims.pop()
+    return torch.Size(dims)
 
 
 def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=False, is_text_model=False, *,
                    device=None, detect_arch=None, upload_threads=0):
-    """Read state dict as ``GGMLTensor``s (loader.py:51-141).
+    """Read a GGUF file as a state dict of ``GGMLTensor`` (loader.py:51-141).
 
     ``device=None`` (the reference's behaviour): every tensor is a read-only mmap view on the CPU.
-    ``device="cuda:N"``: the file's tensor-data section is streamed into ONE HBM buffer and every
-    tensor is a view into it -- packed weights resident, 16-byte aligned, ready for the HIP kernels
-    (``GGUFFile.upload``; the arena is kept alive by the views).
+    ``device="cuda:N"``: the file's tensor-data section is streamed into ONE HBM buffer and every tensor is a
+    view into it -- packed weights resident, 16-byte aligned, ready for the HIP kernels (``GGUFFile.upload``;
+    the views keep the arena alive).
     """
-    reader = GGUFFile(path)
-    try:
-        # filter and strip prefix
-        has_prefix = False
-        if handle_prefix is not None:
-            prefix_len = len(handle_prefix)
-            has_prefix = any(t.name.startswith(handle_prefix) for t in reader.tensors)
-
-        tensors = []
-        for tensor in reader.tensors:
-            sd_key = tensor_name = tensor.name
-            if has_prefix:
-                if not tensor_name.startswith(handle_prefix):
-                    continue
-                sd_key = tensor_name[prefix_len:]
-            tensors.append((sd_key, tensor))
-
-        # detect and verify architecture
-        compat = None
-        arch_str = get_field(reader, "general.architecture", str)
-        type_str = get_field(reader, "general.type", str)
-        if arch_str in [None, "pig", "cow"]:
-            if is_text_model:
-                raise ValueError(f"This gguf file is incompatible with llama.cpp!\nConsider using safetensors or a compatible gguf file\n({path})")
-            compat = "sd.cpp" if arch_str is None else arch_str
-            try:
-                if detect_arch is None:
-                    raise NotImplementedError("no architecture metadata and no detect_arch callable supplied")
-                arch_str = detect_arch(set(val[0] for val in tensors)).arch
-            except Exception as e:
-                raise ValueError(f"This model is not currently supported - ({e})")
-        elif arch_str not in TXT_ARCH_LIST and is_text_model:
-            if type_str not in VIS_TYPE_LIST:
-                raise ValueError(f"Unexpected text model architecture type in GGUF file: {arch_str!r}")
-        elif arch_str not in IMG_ARCH_LIST and not is_text_model:
-            raise ValueError(f"Unexpected architecture type in GGUF file: {arch_str!r}")
-
+    with GGUFFile(path) as reader:
+        selected = _select(reader, handle_prefix)
+        arch, compat = _architecture(reader, path, [key for key, _ in selected], is_text_model, detect_arch)
         if compat:
-            logging.warning(f"Warning: This gguf model file is loaded in compatibility mode '{compat}' [arch:{arch_str}]")
+            logging.warning(f"Warning: This gguf model file is loaded in compatibility mode '{compat}' [arch:{arch}]")
 
-        arena = reader.upload(device, threads=upload_threads) if device is not None else None
+        arena = None if device is None else reader.upload(device, threads=upload_threads)
+        state_dict, counts = {}, {}
+        for key, tensor in selected:
+            raw = tensor.data if arena is None else reader.device_bytes(arena, tensor)
+            shape = _logical_shape(reader, tensor, arch, compat)
+            plain = _PLAIN_DTYPES.get(tensor.tensor_type)
+            if plain is not None:
+                raw = raw.view(plain).view(*shape)
+            entry = GGMLTensor(raw, tensor_type=tensor.tensor_type, tensor_shape=shape)
+            if tensor.tensor_type == Q.BF16 and len(shape) <= 1:
+                entry = dequantize_tensor(entry, dtype=torch.float32)      # norms / biases stored as BF16: plain fp32 from here on
+            state_dict[key] = entry
+            label = getattr(tensor.tensor_type, "name", repr(tensor.tensor_type))
+            counts[label] = counts.get(label, 0) + 1
+        logging.info("gguf qtypes: " + ", ".join(f"{name} ({n})" for name, n in counts.items()))
 
-        # main loading loop
-        state_dict = {}
-        qtype_dict = {}
-        for sd_key, tensor in tensors:
-            tensor_name = tensor.name
-            torch_tensor = reader.device_bytes(arena, tensor) if arena is not None else tensor.data
+    # the VRAM estimate reserves room for dequantizing the largest quantized tensor (ops.py:134-136,151-156)
+    quantized = [key for key, value in state_dict.items() if is_quantized(value)]
+    if quantized:
+        state_dict[max(quantized, key=lambda key: state_dict[key].numel())].is_largest_weight = True
 
-            shape = get_orig_shape(reader, tensor_name)
-            if shape is None:
-                shape = torch.Size(tuple(int(v) for v in reversed(tensor.shape)))
-                # Workaround for stable-diffusion.cpp SDXL detection.
-                if compat == "sd.cpp" and arch_str == "sdxl":
-                    if any([tensor_name.endswith(x) for x in (".proj_in.weight", ".proj_out.weight")]):
-                        while len(shape) > 2 and shape[-1] == 1:
-                            shape = shape[:-1]
-
-            # add to state dict
-            if tensor.tensor_type in {Q.F32, Q.F16}:
-                torch_tensor = torch_tensor.view(torch.float32 if tensor.tensor_type == Q.F32 else torch.float16).view(*shape)
-            state_dict[sd_key] = GGMLTensor(torch_tensor, tensor_type=tensor.tensor_type, tensor_shape=shape)
-
-            # 1D tensors shouldn't be quantized, this is a fix for BF16
-            if len(shape) <= 1 and tensor.tensor_type == Q.BF16:
-                state_dict[sd_key] = dequantize_tensor(state_dict[sd_key], dtype=torch.float32)
-
-            # keep track of loaded tensor types
-            tensor_type_str = getattr(tensor.tensor_type, "name", repr(tensor.tensor_type))
-            qtype_dict[tensor_type_str] = qtype_dict.get(tensor_type_str, 0) + 1
-
-        # print loaded tensor type counts
-        logging.info("gguf qtypes: " + ", ".join(f"{k} ({v})" for k, v in qtype_dict.items()))
-
-        # mark largest tensor for vram estimation
-        qsd = {k: v for k, v in state_dict.items() if is_quantized(v)}
-        if len(qsd) > 0:
-            max_key = max(qsd.keys(), key=lambda k: qsd[k].numel())
-            state_dict[max_key].is_largest_weight = True
-    finally:
-        reader.close()
-
-    if return_arch:
-        return (state_dict, arch_str)
-    return state_dict
+    return (state_dict, arch) if return_arch else state_dict
 
 
 def state_dict_plan(state_dict, dtype=torch.float16, dequant_dtype=None):
