@@ -339,6 +339,52 @@ def test_outputs_beyond_4_gib(pkg, name, out):
     torch.cuda.empty_cache()
 
 
+def test_reentrant_from_threads_and_never_synchronises(pkg):
+    """SURVEY.md section 8b "Threading": re-entrant (no locks, no mutable globals), enqueues on the calling
+    thread's current stream, and returns without waiting for the device."""
+    import threading
+    Q = pkg.qtypes.Q
+    # (1) the call returns while earlier work on the stream is still running
+    big = pkg.synth.make_blocks(Q.Q4_K, 3072 * 12288 // 256, seed=70)
+    dbig = torch.from_numpy(big.reshape(-1).copy()).to(DEV)
+    small = pkg.synth.make_blocks(Q.Q4_K, 16, seed=71)
+    dsmall = torch.from_numpy(small.reshape(-1).copy()).to(DEV)
+    torch.cuda.synchronize()
+    for _ in range(40):                                                      # ~40 x 17 us of queued GPU work
+        pkg.dequant.dequantize(dbig, Q.Q4_K, (3072, 12288))
+    ev = torch.cuda.Event()
+    ev.record()
+    out = pkg.dequant.dequantize(dsmall, Q.Q4_K, (16, 256))
+    assert not ev.query(), "dequantize() waited for the device"
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits16(out), oracle.dequant_f16(Q.Q4_K, small).view(np.uint16))
+
+    # (2) four host threads, each on its own stream, different formats, interleaved calls
+    errors = []
+
+    def worker(i, q):
+        try:
+            bs, _ = pkg.qtypes.block_geometry(q)
+            stream = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(stream):
+                for rep in range(25):
+                    n = 200 + 37 * rep + i
+                    blocks = pkg.synth.make_blocks(q, n, seed=1000 * i + rep, mode="signed")
+                    got = pkg.dequant.dequantize(torch.from_numpy(blocks.reshape(-1).copy()).to(DEV, non_blocking=True), q, (n, bs))
+                    stream.synchronize()
+                    if not np.array_equal(_bits16(got), oracle.dequant_f16(q, blocks).view(np.uint16)):
+                        errors.append((q.name, rep))
+        except Exception as e:                                               # noqa: BLE001 -- surfaced below
+            errors.append((q.name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i, q)) for i, q in enumerate((Q.Q4_K, Q.Q8_0, Q.Q6_K, Q.IQ4_XS))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_capturable_in_a_hip_graph(pkg):
     """The launch only enqueues on torch's current stream and never synchronises, so dequant + F.linear can be
     captured once (torch.cuda.graph -> hipGraph) and replayed -- the launch-bound per-layer loop as one graph."""
