@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the REFERENCE's own torch-CPU dequant (dequant.py, imported verbatim from /root/reference) and
+"""TEST INFRASTRUCTURE (oracle/).  Time the REFERENCE's own torch-CPU dequant (dequant.py, imported verbatim from /root/reference) and
 the C oracle on the same packed bytes, on THIS machine's host cores.  Only runs where /root/reference
 exists (the build container, not the GPU box); the figure goes into DESIGN.md as context for bench.py's
 `cpu_baseline` (kind "port"), which is the only CPU leg that can run beside the GPU."""
@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # oracle/ lives at the repo root
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from oracle import reference  # noqa: E402
