@@ -4,6 +4,7 @@
 #include "../../include/ggq.h"
 #include "../../include/ggq_gguf.h"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 #include <algorithm>
@@ -20,15 +21,44 @@ using namespace ggq;
 //     2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
 // The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
 // artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
+//   * XCD-aware workgroup -> group mapping on LARGE launches (profiles/r01_microbench_l_xcd_run_mapping.txt): inside each
+//     tile of 512 workgroups every XCD takes a run of 64 consecutive groups (256 KiB of fp16 output) instead of every
+//     eighth group.  Interleaved A/B on 3 G-element pools: +1...+5 % for the 4/5/6/8-bit formats, -4 % for Q2_K / Q3_K
+//     and -1.5 % for Q5_1 (those keep the identity mapping); on 47 M-element launches it costs 1-3 %, so launches
+//     below XRUN_MIN_GROUPS keep the identity mapping too.  Shorter runs (4-48) lose 5-10 %.
 template <class F> struct Tune {
     static constexpr int G = (F::BS == 256) ? 8 : 64;
     static constexpr bool DIRECT = false;
     static constexpr bool NTL = true, NTS = true;
     static constexpr int WAVES = 1;
+    static constexpr uint32_t XRUN_LOG2 = 6;
 };
-template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
-template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
-template <> struct Tune<FmtQ6_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; };
+template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
+template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
+template <> struct Tune<FmtQ6_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 6; };
+template <> struct Tune<FmtQ5_1> { static constexpr int G = 64; static constexpr bool DIRECT = false, NTL = true, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
+
+constexpr uint64_t XRUN_MIN_GROUPS = 65536;     // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
+
+// GGQ_XRUN_LOG2 (environment, read once): force the run length for every format and size (0 = identity mapping
+// everywhere, 6 = runs of 64, ...) -- a measurement knob for A/B runs of bench.py, not a user setting.
+int xrun_override()
+{
+    static const int v = [] {
+        const char* e = getenv("GGQ_XRUN_LOG2");
+        if (!e || !*e) return -1;
+        const int x = atoi(e);
+        return (x >= 0 && x <= 16) ? x : -1;
+    }();
+    return v;
+}
+
+template <class F> uint32_t xrun_for(uint64_t groups)
+{
+    const int o = xrun_override();
+    if (o >= 0) return (uint32_t)o;
+    return groups >= XRUN_MIN_GROUPS ? Tune<F>::XRUN_LOG2 : 0u;
+}
 
 thread_local int t_last_hip = 0;
 constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
@@ -44,7 +74,7 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups);
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups, xrun_for<F>(groups));
     return hipGetLastError();
 }
 
@@ -55,7 +85,7 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t 
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups));
     return hipGetLastError();
 }
 

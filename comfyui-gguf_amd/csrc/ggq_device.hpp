@@ -578,7 +578,7 @@ GGQ_DEV void store_throttle()
     if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
 }
 
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -661,18 +661,31 @@ struct Engine {
         }
     }
 
+    // xrun_log2 (wave-uniform kernel argument, 0 = off): the run-length form of the XCD >= 2 mapping below,
+    // chosen per launch by the host (it pays on large launches only; profiles/r01_microbench_l_*).
     template <class Locate>
-    GGQ_DEV static void run(uint64_t total_groups, Locate locate)
+    GGQ_DEV static void run(uint64_t total_groups, uint32_t xrun_log2, Locate locate)
     {
         __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : WAVES * SLICE];
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int lane = (int)(threadIdx.x & 63);
         uint32_t bid = blockIdx.x;
-        if constexpr (XCD) {
-            // workgroup b runs on XCD b % 8 (observed dispatch order, a speed hint only): give each
-            // XCD one contiguous eighth of the work instead of every eighth workgroup.
+        // workgroup b runs on XCD b % 8 (observed dispatch order; a speed hint only, never correctness)
+        if constexpr (XCD == 1) {
+            // give each XCD one contiguous eighth of the work instead of every eighth workgroup
             const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = bid & 7u;
             bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        } else if constexpr (XCD >= 2) {
+            // runs: inside every tile of 8*XCD consecutive workgroups, XCD x takes XCD CONSECUTIVE groups, so
+            // the 128-B line two neighbouring groups share (formats whose group size is not a multiple of
+            // 128 B) is fetched into ONE L2 instead of two; the tile as a whole still streams 8*XCD*4 KiB
+            // of output together.  The last, partial tile keeps the identity mapping.
+            constexpr uint32_t T = 8u * (uint32_t)XCD;
+            const uint32_t tile = bid / T, in = bid % T;
+            if ((tile + 1) * T <= gridDim.x) bid = tile * T + (in & 7u) * (uint32_t)XCD + (in >> 3);
+        } else if (xrun_log2 != 0) {
+            const uint32_t tl = xrun_log2 + 3u, tile = bid >> tl, in = bid & ((1u << tl) - 1u);
+            if (((tile + 1) << tl) <= gridDim.x) bid = (tile << tl) + ((in & 7u) << xrun_log2) + (in >> 3);
         }
         const uint64_t g = (uint64_t)bid * WAVES + (uint64_t)wave;
         if (g >= total_groups) return;
@@ -700,17 +713,17 @@ struct Engine {
 };
 
 // one tensor, descriptor by value
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
-__global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups)
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+__global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups, uint32_t xrun_log2)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, bool XCD = false, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
-__global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups)
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+__global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;

@@ -265,7 +265,7 @@ static Pool make_pool(const QT& q, int pairs)
 static void free_pool(Pool& P) { HIP_CHECK(hipFree(P.packed)); HIP_CHECK(hipFree(P.out)); }
 
 // parity of an arbitrary instantiation (variants other than the shipped one) vs the oracle
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT = false, int THR = -1, int R = 1>
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT = false, int THR = -1, int R = 1>
 static bool check_variant()
 {
     const QT* q = nullptr;
@@ -281,7 +281,7 @@ static bool check_variant()
         HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
         const uint64_t groups = (n + G * R - 1) / (G * R);
         hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3((uint32_t)((groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
-                           ggq::Desc{dp, dout, n, 0}, groups);
+                           ggq::Desc{dp, dout, n, 0}, groups, 0u);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
         uint8_t guard[256]; HIP_CHECK(hipMemcpy(guard, dout + n * F::BS * 2, 256, hipMemcpyDeviceToHost));
@@ -292,7 +292,7 @@ static bool check_variant()
     return ok;
 }
 
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT = false, int THR = -1>
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT = false, int THR = -1>
 static void time_variant(const char* name, Pool& P, Timer& T)
 {
     const bool ok = check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR>();
@@ -303,7 +303,7 @@ static void time_variant(const char* name, Pool& P, Timer& T)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     double med, mn;
-    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups); }, 3, 31, med, mn);
+    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u); }, 3, 31, med, mn);
     const double bytes = (double)P.elements * (2.0 + (double)P.ts / P.bs);
     printf("VAR %-6s %s thr=%-2d G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, DIRECT ? "direct" : "lds   ", THR, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
            (unsigned long long)blocks, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6, ok ? "ok" : "MISMATCH");
@@ -414,7 +414,7 @@ static void skeletons()
 }
 
 // ---- counter study: a fixed sequence of kernel variants for rocprofv3 --pmc passes
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT, int THR>
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT, int THR>
 static void launch3(Pool& P)
 {
     std::vector<ggq::Desc> d = P.descs;
@@ -424,7 +424,7 @@ static void launch3(Pool& P)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups);
+        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipFree(dt));
 }
@@ -485,8 +485,8 @@ struct AB {
     }
 };
 
-template <class F, int G, bool NTL, bool NTS, int WAVES, bool XCD, bool DIRECT, int THR, int R = 1>
-static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0)
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT, int THR, int R = 1>
+static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t xrun = 0)
 {
     std::vector<ggq::Desc> d = P.descs;
     uint64_t groups = 0;
@@ -496,9 +496,9 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0)
     ab.to_free.push_back(dt);
     const uint32_t blocks = (uint32_t)((groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
     char buf[128];
-    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, THR, dyn_lds / 1024);
+    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun ? (1u << xrun) : 0u, THR, dyn_lds / 1024);
     if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
-    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups); },
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R>()});
 }
 
@@ -554,6 +554,41 @@ static void ab_big(const char* name, int qi, int pairs)
     ab_add<F, G, false, true, 1, false, true, -1>(ab, name, P);
     ab.run(9, 3);
     free_pool(P);
+}
+
+// XCD-aware run mapping (Engine XCD >= 2) against the identity mapping, shipped launch shape otherwise
+template <class F, int G, bool NTL>
+static void ab_xcd(const char* name, int qi, int pairs = 64)
+{
+    Pool P = make_pool(QTS[qi], pairs);
+    printf("POOL %s pairs=%d\n", name, pairs);
+    AB ab;
+    ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 1, 1, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 1, 48, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 1, 64, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 1, 96, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 1, 128, false, -1>(ab, name, P);
+    ab.run(9, 3);
+    free_pool(P);
+}
+
+static void ab_xcd_all()
+{
+    for (int pairs : {64, 2}) {
+        ab_xcd<ggq::FmtQ4_0, 64, true>("Q4_0", 0, pairs);
+        ab_xcd<ggq::FmtQ4_1, 64, true>("Q4_1", 1, pairs);
+        ab_xcd<ggq::FmtQ5_0, 64, true>("Q5_0", 2, pairs);
+        ab_xcd<ggq::FmtQ5_1, 64, true>("Q5_1", 3, pairs);
+        ab_xcd<ggq::FmtQ8_0, 64, true>("Q8_0", 4, pairs);
+        ab_xcd<ggq::FmtQ2_K, 8, false>("Q2_K", 5, pairs);
+        ab_xcd<ggq::FmtQ3_K, 8, false>("Q3_K", 6, pairs);
+        ab_xcd<ggq::FmtQ4_K, 8, true>("Q4_K", 7, pairs);
+        ab_xcd<ggq::FmtQ5_K, 8, true>("Q5_K", 8, pairs);
+        ab_xcd<ggq::FmtQ6_K, 8, false>("Q6_K", 9, pairs);
+        ab_xcd<ggq::FmtIQ4_NL, 64, true>("IQ4_NL", 10, pairs);
+        ab_xcd<ggq::FmtIQ4_XS, 8, true>("IQ4_XS", 11, pairs);
+    }
 }
 
 static void ab_all()
@@ -657,5 +692,6 @@ int main(int argc, char** argv)
     if (what == "skel") skeletons();
     if (what == "pmc2") pmc2_sequence();
     if (what == "ab") ab_all();
+    if (what == "abxcd") ab_xcd_all();
     return rc ? 1 : 0;
 }

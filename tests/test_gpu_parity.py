@@ -294,6 +294,33 @@ def test_plan_mixed_qtypes_matches_per_tensor(pkg):
     plan.close(); plan2.close(); plan3.close()
 
 
+def test_large_plan_uses_the_xcd_run_mapping_and_stays_exact(pkg):
+    """Launches of >= 65536 groups switch to the XCD-aware workgroup -> group mapping (a permutation of which
+    workgroup does which group, ggq_capi.hip Tune<>): every tensor of a 0.9 G-element two-format plan is
+    checked in full against the oracle's SIMD leg and in windows against the soft-float checker."""
+    Q = pkg.qtypes.Q
+    items, packed = [], []
+    for i in range(24):
+        q = Q.Q4_K if i % 2 == 0 else Q.Q8_0
+        p = pkg.synth.make_tensor_bytes(q, (3072, 12288), seed=300 + i, mode="signed")
+        packed.append((q, p))
+        items.append((torch.from_numpy(p).to(DEV), q, (3072, 12288)))
+    plan = pkg.grouped.DequantPlan(items)
+    assert plan.kernels == 2
+    outs = plan.launch()
+    torch.cuda.synchronize()
+    for (q, p), out in zip(packed, outs):
+        got = _bits16(out)
+        if oracle.simd_available():
+            assert np.array_equal(got, oracle.dequant_f16(q, p, simd=True).view(np.uint16)), q
+        bs, ts = pkg.qtypes.block_geometry(q)
+        n_blocks = p.size // ts
+        for b0 in (0, n_blocks // 3, n_blocks - 4096):
+            want = oracle.dequant_f16(q, p[b0 * ts:(b0 + 4096) * ts]).view(np.uint16)
+            assert np.array_equal(got[b0 * bs:(b0 + 4096) * bs], want), (q, b0)
+    plan.close()
+
+
 def test_ggml_linear_forward_is_the_reference_call_chain(pkg):
     """GGMLOps.Linear's hot loop (ops.py:242-244): dequantize the weight on every forward, then F.linear."""
     Q = pkg.qtypes.Q
