@@ -684,6 +684,8 @@ struct Engine {
             const uint32_t tile = bid / T, in = bid % T;
             if ((tile + 1) * T <= gridDim.x) bid = tile * T + (in & 7u) * (uint32_t)XCD + (in >> 3);
         } else if (xrun_log2 != 0) {
+            // What matters (profiles/r01_microbench_l/m/n): every XCD keeps the SAME slot of every tile (rotating the slot
+            // with the tile index loses 10 %; which XCD gets which slot is irrelevant, as is the walk direction).
             const uint32_t tl = xrun_log2 + 3u, tile = bid >> tl, in = bid & ((1u << tl) - 1u);
             if (((tile + 1) << tl) <= gridDim.x) bid = (tile << tl) + ((in & 7u) << xrun_log2) + (in >> 3);
         }

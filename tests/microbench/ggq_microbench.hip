@@ -496,7 +496,7 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
     ab.to_free.push_back(dt);
     const uint32_t blocks = (uint32_t)((groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
     char buf[128];
-    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun ? (1u << xrun) : 0u, THR, dyn_lds / 1024);
+    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun, THR, dyn_lds / 1024);
     if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
     ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R>()});
@@ -556,19 +556,19 @@ static void ab_big(const char* name, int qi, int pairs)
     free_pool(P);
 }
 
-// XCD-aware run mapping (Engine XCD >= 2) against the identity mapping, shipped launch shape otherwise
+// XCD-aware run mapping (runtime xrun argument = log2 of the run length; template XCD = 1: one eighth per XCD)
+// against the identity mapping, shipped launch shape otherwise.  profiles/r01_microbench_l (template runs of
+// 48/64/96/128), _m (slot rotation, reversed walk, 2 waves) and _n (slot permutations) were taken with
+// experimental variants of this function that have since been removed from the engine.
 template <class F, int G, bool NTL>
 static void ab_xcd(const char* name, int qi, int pairs = 64)
 {
     Pool P = make_pool(QTS[qi], pairs);
     printf("POOL %s pairs=%d\n", name, pairs);
     AB ab;
-    ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P);
+    for (uint32_t xr : {0u, 5u, 6u, 7u, 8u}) ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P, 0, xr);
     ab_add<F, G, NTL, true, 1, 1, false, -1>(ab, name, P);
-    ab_add<F, G, NTL, true, 1, 48, false, -1>(ab, name, P);
-    ab_add<F, G, NTL, true, 1, 64, false, -1>(ab, name, P);
-    ab_add<F, G, NTL, true, 1, 96, false, -1>(ab, name, P);
-    ab_add<F, G, NTL, true, 1, 128, false, -1>(ab, name, P);
+    ab_add<F, G, NTL, true, 2, 0, false, -1>(ab, name, P, 0, 5u);
     ab.run(9, 3);
     free_pool(P);
 }
@@ -577,17 +577,11 @@ static void ab_xcd_all()
 {
     for (int pairs : {64, 2}) {
         ab_xcd<ggq::FmtQ4_0, 64, true>("Q4_0", 0, pairs);
-        ab_xcd<ggq::FmtQ4_1, 64, true>("Q4_1", 1, pairs);
-        ab_xcd<ggq::FmtQ5_0, 64, true>("Q5_0", 2, pairs);
-        ab_xcd<ggq::FmtQ5_1, 64, true>("Q5_1", 3, pairs);
         ab_xcd<ggq::FmtQ8_0, 64, true>("Q8_0", 4, pairs);
         ab_xcd<ggq::FmtQ2_K, 8, false>("Q2_K", 5, pairs);
         ab_xcd<ggq::FmtQ3_K, 8, false>("Q3_K", 6, pairs);
         ab_xcd<ggq::FmtQ4_K, 8, true>("Q4_K", 7, pairs);
-        ab_xcd<ggq::FmtQ5_K, 8, true>("Q5_K", 8, pairs);
         ab_xcd<ggq::FmtQ6_K, 8, false>("Q6_K", 9, pairs);
-        ab_xcd<ggq::FmtIQ4_NL, 64, true>("IQ4_NL", 10, pairs);
-        ab_xcd<ggq::FmtIQ4_XS, 8, true>("IQ4_XS", 11, pairs);
     }
 }
 
