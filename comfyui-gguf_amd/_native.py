@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
-LIB_PATH = os.path.join(LIB_DIR, "libggq_hip.so")
+# GGQ_HIP_LIB: load another build of the library (A/B measurements); default = the in-tree build
+LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
 ABI_VERSION = 2

@@ -14,31 +14,52 @@ namespace {
 using namespace ggq;
 
 // Launch geometry, chosen by interleaved A/B runs on MI355X over pools whose PACKED bytes alone are
-// 4-12x the 256 MiB Infinity Cache (DESIGN.md section 4 "Tuning", profiles/r01_microbench_j_*):
-//   * one group of 2048 output elements per wavefront, staged through a wave-private LDS slice;
-//   * one wave per workgroup (0.5-4 % better than four, never worse);
+// 4-12x the 256 MiB Infinity Cache (DESIGN.md section 4 "Tuning", profiles/r01_microbench_*):
+//   * TEAM: who owns a group.  "solo" = one wavefront owns 2048 output elements from first load to last store, one
+//     wave per workgroup (0.5-4 % better than four independent waves).  "coop" = the 4 waves of a workgroup own 4096
+//     elements together (one shared LDS slice, one s_barrier): the load is spread over 256 threads and every wave
+//     stores 2 rows instead of 4 back to back.  Shipped where BOTH the torch-free harness and bench.py (same box,
+//     alternating builds) agree: Q8_0 +6.2 % (the format with the most packed bytes per group: 2176 B), Q4_1 +1.6 %,
+//     Q5_1 +1.2 % as 2 waves x 2048 elements.  The harness also showed Q6_K +5.5 %, Q5_K +3.5 %, Q5_0 +3.4 %
+//     (profiles/r01_microbench_o_coop_teams.txt) but bench.py, whose tensors are separate 2 MiB-aligned allocations,
+//     measured -0.4 %, -3.5 %, -0.9 % for them, so they stay solo, as do the 4-bit formats (+-0.7 % either way) and
+//     Q2_K / Q3_K (-4...-6 % with any coop shape).  One row per wave (4 waves x 2048) halves the rate: the per-wave
+//     fixed cost dominates.
 //   * non-temporal stores (+3-4 %); non-temporal loads are a wash for the 4/5/8-bit formats and cost
 //     2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
+//   * XCD-aware workgroup -> group mapping on LARGE launches (profiles/r01_microbench_l_xcd_run_mapping.txt): inside each
+//     tile every XCD takes a run of consecutive groups covering 256 KiB of fp16 output (64 solo groups, 32 coop groups)
+//     instead of every eighth group.  Interleaved A/B on 3 G-element pools: +1...+5 % for the 4/5/6/8-bit formats, -4 %
+//     for Q2_K / Q3_K and -1.5 % for Q5_1 (those keep the identity mapping); on 47 M-element launches it costs 1-3 %, so
+//     launches below XRUN_MIN_ELEMENTS keep the identity mapping too.  Shorter runs lose 5-10 %.
 // The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
 // artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
-//   * XCD-aware workgroup -> group mapping on LARGE launches (profiles/r01_microbench_l_xcd_run_mapping.txt): inside each
-//     tile of 512 workgroups every XCD takes a run of 64 consecutive groups (256 KiB of fp16 output) instead of every
-//     eighth group.  Interleaved A/B on 3 G-element pools: +1...+5 % for the 4/5/6/8-bit formats, -4 % for Q2_K / Q3_K
-//     and -1.5 % for Q5_1 (those keep the identity mapping); on 47 M-element launches it costs 1-3 %, so launches
-//     below XRUN_MIN_GROUPS keep the identity mapping too.  Shorter runs (4-48) lose 5-10 %.
-template <class F> struct Tune {
+template <class F> struct Tune {                 // default: solo teams, NT loads, runs of 64 groups
     static constexpr int G = (F::BS == 256) ? 8 : 64;
-    static constexpr bool DIRECT = false;
-    static constexpr bool NTL = true, NTS = true;
+    static constexpr bool COOP = false, NTL = true, NTS = true;
     static constexpr int WAVES = 1;
     static constexpr uint32_t XRUN_LOG2 = 6;
 };
-template <> struct Tune<FmtQ2_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
-template <> struct Tune<FmtQ3_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
-template <> struct Tune<FmtQ6_K> { static constexpr int G = 8; static constexpr bool DIRECT = false, NTL = false, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 6; };
-template <> struct Tune<FmtQ5_1> { static constexpr int G = 64; static constexpr bool DIRECT = false, NTL = true, NTS = true; static constexpr int WAVES = 1; static constexpr uint32_t XRUN_LOG2 = 0; };
+#define GGQ_TUNE(F, G_, COOP_, WAVES_, NTL_, XRUN_)                                              \
+    template <> struct Tune<F> {                                                                 \
+        static constexpr int G = G_, WAVES = WAVES_;                                             \
+        static constexpr bool COOP = COOP_, NTL = NTL_, NTS = true;                              \
+        static constexpr uint32_t XRUN_LOG2 = XRUN_;                                             \
+    }
+//       format      G   coop  waves  NT loads  log2(run)
+GGQ_TUNE(FmtQ2_K,    8,  false, 1,    false,    0);
+GGQ_TUNE(FmtQ3_K,    8,  false, 1,    false,    0);
+GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
+#ifdef GGQ_SOLO_ONLY    /* A/B builds only: every format on solo teams, as before the coop engine */
+GGQ_TUNE(FmtQ5_1,   64,  false, 1,    true,     0);
+#else
+GGQ_TUNE(FmtQ8_0,  128,  true,  4,    true,     5);
+GGQ_TUNE(FmtQ4_1,  128,  true,  4,    true,     5);
+GGQ_TUNE(FmtQ5_1,   64,  true,  2,    true,     0);
+#endif
+#undef GGQ_TUNE
 
-constexpr uint64_t XRUN_MIN_GROUPS = 65536;     // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
+constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 
 // GGQ_XRUN_LOG2 (environment, read once): force the run length for every format and size (0 = identity mapping
 // everywhere, 6 = runs of 64, ...) -- a measurement knob for A/B runs of bench.py, not a user setting.
@@ -57,7 +78,7 @@ template <class F> uint32_t xrun_for(uint64_t groups)
 {
     const int o = xrun_override();
     if (o >= 0) return (uint32_t)o;
-    return groups >= XRUN_MIN_GROUPS ? Tune<F>::XRUN_LOG2 : 0u;
+    return groups * (uint64_t)(Tune<F>::G * F::BS) >= XRUN_MIN_ELEMENTS ? Tune<F>::XRUN_LOG2 : 0u;
 }
 
 thread_local int t_last_hip = 0;
@@ -72,9 +93,9 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     using T = Tune<F>;
     const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
     if (groups == 0) return hipSuccess;
-    const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
+    const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups, xrun_for<F>(groups));
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups, xrun_for<F>(groups));
     return hipGetLastError();
 }
 
@@ -83,9 +104,9 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t 
 {
     using T = Tune<F>;
     if (groups == 0) return hipSuccess;
-    const uint64_t blocks = (groups + T::WAVES - 1) / T::WAVES;
+    const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, false, T::DIRECT, -1, 1, ARITH>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups));
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups));
     return hipGetLastError();
 }
 

@@ -578,7 +578,7 @@ GGQ_DEV void store_throttle()
     if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
 }
 
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -588,20 +588,30 @@ struct Engine {
     // address below it, keeping the same byte offset inside its LDS slice.
     static constexpr bool ALIGNED = GROUP_BYTES % 16 == 0;
     static constexpr int UNITS = (GROUP_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;   // 16-B load units per group (max)
-    static constexpr int NU = (UNITS + 63) / 64;       // per lane
+    // TEAM = the threads that own one group: a wavefront, or (COOP) the whole workgroup -- then every wave stores ONE
+    // 1-KiB row instead of four back to back, which the memory system takes 6 % faster (tests/microbench `fillrows`).
+    static constexpr int TEAM = COOP ? WAVES * 64 : 64;
+    static constexpr int NU = (UNITS + TEAM - 1) / TEAM;   // loads per thread
     static constexpr int CHUNKS = G * CPB;
     static constexpr int PIECES = Layout<OUT>::PIECES;  // lanes per chunk (2 for fp32 output: one quad each)
-    static constexpr int NCH = CHUNKS * PIECES / 64;   // stores per lane per group
-    static constexpr int SLICE = NU * 64 * 16;         // LDS bytes per wave
+    static constexpr int NCH = CHUNKS * PIECES / TEAM; // stores per thread per group
+    static constexpr int SLICE = NU * TEAM * 16;       // LDS bytes per team
     static constexpr int THREADS = WAVES * 64;
     static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
     static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
-    static_assert((CHUNKS * PIECES) % 64 == 0, "a group must be a whole number of 1 KiB store rows");
+    static_assert((CHUNKS * PIECES) % TEAM == 0, "a group must be a whole number of 1 KiB store rows per wave");
+    static_assert(!(COOP && DIRECT) && !(COOP && R != 1), "COOP is the LDS-staged single-pass engine");
+
+    GGQ_DEV static void team_sync()
+    {
+        if constexpr (COOP) __syncthreads();             // s_barrier over the workgroup's waves
+        else wave_sync();
+    }
 
     // FULL = the whole group lies inside the tensor (wave-uniform): no per-lane bounds checks,
     // so the compiler batches the LDS reads of all NCH chunks.
     template <bool FULL>
-    GGQ_DEV static void body(uint8_t* slice, const Work& w, int lane)
+    GGQ_DEV static void body(uint8_t* slice, const Work& w, int lane)      // lane = index inside the team
     {
         const uint64_t off = w.lg * (uint64_t)GROUP_BYTES;
         const uint32_t a = ALIGNED ? 0u : ((uint32_t)off & 15u);            // wave-uniform
@@ -614,8 +624,8 @@ struct Engine {
         u32x4 pf[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const uint32_t o = (uint32_t)(lane + 64 * u) * 16u;
-            if (FULL && ALIGNED && (u + 1) * 64 <= UNITS) {
+            const uint32_t o = (uint32_t)(lane + TEAM * u) * 16u;
+            if (FULL && ALIGNED && (u + 1) * TEAM <= UNITS) {
                 pf[u] = gload16<NTL>(base + o);
             } else {
                 // the last unit of a tensor may straddle its end: an aligned 16-B read never crosses
@@ -624,12 +634,12 @@ struct Engine {
             }
         }
 #pragma unroll
-        for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
-        wave_sync();
+        for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + TEAM * u) * 16) = pf[u];
+        team_sync();
         const uint64_t b0 = w.lg * (uint64_t)G;
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
-            const int unit = lane + 64 * s;
+            const int unit = lane + TEAM * s;
             const int chunk = unit / PIECES, piece = unit % PIECES;
             const int bl = chunk / CPB, j = chunk % CPB;
             const uint64_t gb = b0 + (uint64_t)bl;
@@ -666,9 +676,9 @@ struct Engine {
     template <class Locate>
     GGQ_DEV static void run(uint64_t total_groups, uint32_t xrun_log2, Locate locate)
     {
-        __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : WAVES * SLICE];
-        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int lane = (int)(threadIdx.x & 63);
+        __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : (COOP ? 1 : WAVES) * SLICE];
+        const int wave = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int lane = COOP ? (int)threadIdx.x : (int)(threadIdx.x & 63);
         uint32_t bid = blockIdx.x;
         // workgroup b runs on XCD b % 8 (observed dispatch order; a speed hint only, never correctness)
         if constexpr (XCD == 1) {
@@ -689,10 +699,10 @@ struct Engine {
             const uint32_t tl = xrun_log2 + 3u, tile = bid >> tl, in = bid & ((1u << tl) - 1u);
             if (((tile + 1) << tl) <= gridDim.x) bid = (tile << tl) + ((in & 7u) << xrun_log2) + (in >> 3);
         }
-        const uint64_t g = (uint64_t)bid * WAVES + (uint64_t)wave;
+        const uint64_t g = COOP ? (uint64_t)bid : (uint64_t)bid * WAVES + (uint64_t)wave;
         if (g >= total_groups) return;
         const Work w0 = locate(g);                       // lg counts units of R*G blocks
-        uint8_t* slice = smem + (DIRECT ? 0 : wave * SLICE);
+        uint8_t* slice = smem + (DIRECT ? 0 : wave * SLICE);          // COOP: wave == 0, one slice per workgroup
         // R > 1: the wave walks R consecutive groups strictly one after the other -- load, unpack,
         // store, wait for the store -- so it never has more than one group's traffic in flight.
 #pragma unroll 1
@@ -715,17 +725,17 @@ struct Engine {
 };
 
 // one tensor, descriptor by value
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups, uint32_t xrun_log2)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH>::run(total_groups, xrun_log2, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;

@@ -205,6 +205,82 @@ __global__ __launch_bounds__(256) void k_mix(const ggq::u32x4* in, ggq::u32x4* o
     }
 }
 
+// the same streams as one-shot 4 KiB workgroups (256 threads x 16 B) with the engine's XCD run mapping (xr = log2 run, 0 = off)
+__device__ __forceinline__ uint32_t xmap(uint32_t bid, uint32_t xr)
+{
+    if (xr == 0) return bid;
+    const uint32_t tl = xr + 3u, tile = bid >> tl, in = bid & ((1u << tl) - 1u);
+    return (((tile + 1) << tl) <= gridDim.x) ? (tile << tl) + ((in & 7u) << xr) + (in >> 3) : bid;
+}
+template <int MODE>   // 0 fill, 1 copy, 2 mix 9:32 (72 of 256 threads load, everyone stores after a cross-lane dependency)
+__global__ __launch_bounds__(256) void k_stream_x(const ggq::u32x4* in, ggq::u32x4* out, uint32_t xr)
+{
+    const uint64_t t = xmap(blockIdx.x, xr);
+    ggq::u32x4 v{1, 2, 3, (uint32_t)t};
+    if (MODE == 1) v = __builtin_nontemporal_load(in + t * 256 + threadIdx.x);
+    if (MODE == 2) {
+        if (threadIdx.x < 72) v = __builtin_nontemporal_load(in + t * 72 + threadIdx.x);
+        v.x += __shfl(v.y, threadIdx.x & 7);
+    }
+    __builtin_nontemporal_store(v, out + t * 256 + threadIdx.x);
+}
+
+// pure fill, every 4 KiB piece written by ONE workgroup of W waves, each wave writing R = 4 / W rows of 1 KiB
+// (W = 1: the dequant kernels' pattern, one wave stores 4 rows back to back; W = 4: one row per wave)
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_fill_rows(ggq::u32x4* out, uint32_t xr)
+{
+    const uint64_t t = xmap(blockIdx.x, xr);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int R = 4 / W;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        __builtin_nontemporal_store(ggq::u32x4{1, 2, (uint32_t)r, (uint32_t)t}, out + t * 256 + (wave * R + r) * 64 + lane);
+}
+
+static void fill_rows()
+{
+    Timer T; double med, mn;
+    const uint64_t bytes = 6ull << 30;
+    ggq::u32x4* b;
+    HIP_CHECK(hipMalloc(&b, bytes));
+    const uint32_t grid = (uint32_t)(bytes / 4096);
+    for (int rep = 0; rep < 2; rep++)
+        for (uint32_t xr : {0u, 6u}) {
+            T.run([&] { k_fill_rows<1><<<grid, 64>>>(b, xr); }, 2, 9, med, mn);
+            printf("FILLROWS waves=1 rows/wave=4 run=2^%u %8.1f GB/s (median) %8.1f (best)\n", xr, bytes / med / 1e6, bytes / mn / 1e6);
+            T.run([&] { k_fill_rows<2><<<grid, 128>>>(b, xr); }, 2, 9, med, mn);
+            printf("FILLROWS waves=2 rows/wave=2 run=2^%u %8.1f GB/s (median) %8.1f (best)\n", xr, bytes / med / 1e6, bytes / mn / 1e6);
+            T.run([&] { k_fill_rows<4><<<grid, 256>>>(b, xr); }, 2, 9, med, mn);
+            printf("FILLROWS waves=4 rows/wave=1 run=2^%u %8.1f GB/s (median) %8.1f (best)\n", xr, bytes / med / 1e6, bytes / mn / 1e6);
+            fflush(stdout);
+        }
+    HIP_CHECK(hipFree(b));
+}
+
+static void ceilings_x()
+{
+    Timer T; double med, mn;
+    const uint64_t bytes = 6ull << 30;   // 6 GiB written per launch, like the bench pool's output
+    ggq::u32x4 *a, *b;
+    HIP_CHECK(hipMalloc(&a, bytes)); HIP_CHECK(hipMalloc(&b, bytes));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(a), bytes / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    const uint32_t grid = (uint32_t)(bytes / 4096);
+    for (int rep = 0; rep < 2; rep++)
+        for (uint32_t xr : {0u, 4u, 5u, 6u, 7u, 8u, 10u}) {
+            T.run([&] { k_stream_x<0><<<grid, 256>>>(a, b, xr); }, 2, 9, med, mn);
+            printf("CEILX fill  run=2^%-2u %8.1f GB/s (median) %8.1f (best)\n", xr, bytes / med / 1e6, bytes / mn / 1e6);
+            T.run([&] { k_stream_x<1><<<grid, 256>>>(a, b, xr); }, 2, 9, med, mn);
+            printf("CEILX copy  run=2^%-2u %8.1f GB/s (median) %8.1f (best)   [read+write]\n", xr, 2.0 * bytes / med / 1e6, 2.0 * bytes / mn / 1e6);
+            const double mixbytes = (double)grid * (72 + 256) * 16;
+            T.run([&] { k_stream_x<2><<<grid, 256>>>(a, b, xr); }, 2, 9, med, mn);
+            printf("CEILX mix   run=2^%-2u %8.1f GB/s (median) %8.1f (best)   [9:32 read:write]\n", xr, mixbytes / med / 1e6, mixbytes / mn / 1e6);
+            fflush(stdout);
+        }
+    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
+}
+
 static void ceilings()
 {
     Timer T; double med, mn;
@@ -265,7 +341,7 @@ static Pool make_pool(const QT& q, int pairs)
 static void free_pool(Pool& P) { HIP_CHECK(hipFree(P.packed)); HIP_CHECK(hipFree(P.out)); }
 
 // parity of an arbitrary instantiation (variants other than the shipped one) vs the oracle
-template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT = false, int THR = -1, int R = 1>
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT = false, int THR = -1, int R = 1, bool COOP = false>
 static bool check_variant()
 {
     const QT* q = nullptr;
@@ -280,7 +356,7 @@ static bool check_variant()
         HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
         const uint64_t groups = (n + G * R - 1) / (G * R);
-        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3((uint32_t)((groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
                            ggq::Desc{dp, dout, n, 0}, groups, 0u);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
@@ -485,7 +561,7 @@ struct AB {
     }
 };
 
-template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT, int THR, int R = 1>
+template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT, int THR, int R = 1, bool COOP = false>
 static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t xrun = 0)
 {
     std::vector<ggq::Desc> d = P.descs;
@@ -494,12 +570,12 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
     ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     ab.to_free.push_back(dt);
-    const uint32_t blocks = (uint32_t)((groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
-    char buf[128];
-    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, DIRECT ? "direct" : "lds", G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun, THR, dyn_lds / 1024);
-    if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
-    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun); },
-                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R>()});
+    const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, COOP ? "coop" : (DIRECT ? "direct" : "lds"), G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun, THR, dyn_lds / 1024);
+    if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R, COOP>()});
 }
 
 template <class F, int G>
@@ -571,6 +647,39 @@ static void ab_xcd(const char* name, int qi, int pairs = 64)
     ab_add<F, G, NTL, true, 2, 0, false, -1>(ab, name, P, 0, 5u);
     ab.run(9, 3);
     free_pool(P);
+}
+
+// COOP (the workgroup's waves share ONE group; every wave stores fewer rows) against the shipped one-wave teams
+template <class F, int G, bool NTL>
+static void ab_coop(const char* name, int qi, int pairs, uint32_t xr)
+{
+    Pool P = make_pool(QTS[qi], pairs);
+    printf("POOL %s pairs=%d\n", name, pairs);
+    AB ab;
+    ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P, 0, xr);
+    ab_add<F, G, NTL, true, 2, 0, false, -1, 1, true>(ab, name, P, 0, xr);
+    ab_add<F, 2 * G, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, xr > 0 ? xr - 1 : 0);
+    ab_add<F, 2 * G, NTL, true, 2, 0, false, -1, 1, true>(ab, name, P, 0, xr > 0 ? xr - 1 : 0);
+    ab_add<F, 4 * G, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, xr > 1 ? xr - 2 : 0);
+    ab.run(9, 3);
+    free_pool(P);
+}
+
+static void ab_coop_all()
+{
+    for (int pairs : {64, 2}) {
+        const uint32_t xr = pairs == 64 ? 6 : 0;
+        ab_coop<ggq::FmtQ4_0, 64, true>("Q4_0", 0, pairs, xr);
+        ab_coop<ggq::FmtQ4_1, 64, true>("Q4_1", 1, pairs, xr);
+        ab_coop<ggq::FmtQ5_0, 64, true>("Q5_0", 2, pairs, xr);
+        ab_coop<ggq::FmtQ5_1, 64, true>("Q5_1", 3, pairs, 0);
+        ab_coop<ggq::FmtQ8_0, 64, true>("Q8_0", 4, pairs, xr);
+        ab_coop<ggq::FmtQ4_K, 8, true>("Q4_K", 7, pairs, xr);
+        ab_coop<ggq::FmtQ5_K, 8, true>("Q5_K", 8, pairs, xr);
+        ab_coop<ggq::FmtQ6_K, 8, false>("Q6_K", 9, pairs, xr);
+        ab_coop<ggq::FmtIQ4_NL, 64, true>("IQ4_NL", 10, pairs, xr);
+        ab_coop<ggq::FmtIQ4_XS, 8, true>("IQ4_XS", 11, pairs, xr);
+    }
 }
 
 static void ab_xcd_all()
@@ -687,5 +796,8 @@ int main(int argc, char** argv)
     if (what == "pmc2") pmc2_sequence();
     if (what == "ab") ab_all();
     if (what == "abxcd") ab_xcd_all();
+    if (what == "ceilx") ceilings_x();
+    if (what == "abcoop") ab_coop_all();
+    if (what == "fillrows") fill_rows();
     return rc ? 1 : 0;
 }
