@@ -675,15 +675,32 @@ static void ab_coop(const char* name, int qi, int pairs, uint32_t xr)
     free_pool(P);
 }
 
+// Q2_K / Q3_K: their 672 / 880-byte groups share 128-B lines with their neighbours (12-14 % extra reads under the
+// identity mapping); shapes whose groups are whole lines (Q2_K G=32) or that keep neighbours on one XCD
+template <class F, bool NTL>
+static void ab_small_groups(const char* name, int qi)
+{
+    Pool P = make_pool(QTS[qi], 64);
+    printf("POOL %s pairs=64\n", name);
+    AB ab;
+    ab_add<F, 8, NTL, true, 1, 0, false, -1>(ab, name, P, 0, 0);
+    ab_add<F, 8, NTL, true, 1, 0, false, -1>(ab, name, P, 0, 6);
+    ab_add<F, 8, !NTL, true, 1, 0, false, -1>(ab, name, P, 0, 6);
+    ab_add<F, 8, NTL, true, 2, 0, false, -1>(ab, name, P, 0, 0);
+    ab_add<F, 8, NTL, true, 4, 0, false, -1>(ab, name, P, 0, 0);
+    ab_add<F, 16, NTL, true, 1, 0, false, -1>(ab, name, P, 0, 0);
+    ab_add<F, 32, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, 0);
+    ab_add<F, 32, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, 4);
+    ab_add<F, 32, !NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, 4);
+    ab_add<F, 16, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, 5);
+    ab.run(9, 3);
+    free_pool(P);
+}
+
 static void ab_coop_all()
 {
-    printf("pool alignment %llu\n", (unsigned long long)pool_align());
-    const uint32_t xr = 6;
-    ab_coop<ggq::FmtQ5_0, 64, true>("Q5_0", 2, 64, xr);
-    ab_coop<ggq::FmtQ8_0, 64, true>("Q8_0", 4, 64, xr);
-    ab_coop<ggq::FmtQ4_K, 8, true>("Q4_K", 7, 64, xr);
-    ab_coop<ggq::FmtQ5_K, 8, true>("Q5_K", 8, 64, xr);
-    ab_coop<ggq::FmtQ6_K, 8, false>("Q6_K", 9, 64, xr);
+    ab_small_groups<ggq::FmtQ2_K, false>("Q2_K", 5);
+    ab_small_groups<ggq::FmtQ3_K, false>("Q3_K", 6);
 }
 
 static void ab_xcd_all()
@@ -749,7 +766,7 @@ static void pmc_sequence()
     for (int i = 0; i < 3; i++) { k_copy16<<<262144, 256>>>(a, b, n16); k_copy16nt<<<262144, 256>>>(a, b, n16); k_fill16<<<262144, 256>>>(b, n16); k_fill16nt<<<262144, 256>>>(b, n16); }
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
-    for (int qi : {7, 0, 9, 4, 2}) {
+    for (int qi : {7, 0, 9, 4, 2, 5, 6}) {
         Pool P = make_pool(QTS[qi], 64);
         std::vector<ggq_desc> descs;
         for (auto& d : P.descs) descs.push_back(ggq_desc{QTS[qi].id, GGQ_OUT_F16, d.packed, d.out, d.n_blocks});

@@ -26,7 +26,7 @@ def durations(path):
     return {k: sum(v) / len(v) for k, v in d.items()}
 
 
-TS = {"FmtQ4_K": 144 / 256, "FmtQ4_0": 18 / 32, "FmtQ6_K": 210 / 256, "FmtQ8_0": 34 / 32, "FmtQ5_0": 22 / 32}
+TS = {"FmtQ4_K": 144 / 256, "FmtQ4_0": 18 / 32, "FmtQ6_K": 210 / 256, "FmtQ8_0": 34 / 32, "FmtQ5_0": 22 / 32, "FmtQ2_K": 84 / 256, "FmtQ3_K": 110 / 256}
 ELEMENTS = 64 * (3072 * 3072 + 3072 * 12288)
 DT = {"0": "f16", "1": "bf16", "2": "f32"}
 
