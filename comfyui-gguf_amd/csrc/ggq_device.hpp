@@ -1,25 +1,29 @@
 // ggq_device.hpp -- gfx950 (MI355X / CDNA4) device code for GGUF block dequantization.
 //
 // What it computes: the reference's block unpackers (city96/ComfyUI-GGUF dequant.py:65-285),
-// bit-exactly, for the default fp16 arithmetic mode (dequant_dtype=None, nodes.py:152-153):
-// every `*`, `+`, `-` of the reference is ONE fp16 op with ONE rounding here too
-// (v_pk_mul_f16 / v_pk_add_f16; the build uses -ffp-contract=off so that d*q - dm never
-// becomes a v_pk_fma_f16 -- a fused op differs from the reference by up to 1328 ULP on Q4_K,
-// SURVEY.md section 0 finding 3).
+// bit-exactly, in all three arithmetic modes its nodes can select (dequant_dtype None / float16,
+// bfloat16, float32; nodes.py:152-153,186) and with the trailing `.to(dtype)` of dequantize_tensor
+// (dequant.py:23) fused into the store: every `*`, `+`, `-` of the reference is ONE hardware op with
+// ONE rounding here too (v_pk_mul_f16 / v_pk_add_f16; v_mul_f32 / v_sub_f32; the same + v_cvt_pk_bf16_f32).
+// The build uses -ffp-contract=off so that d*q - dm never becomes an FMA -- a fused op differs from the
+// reference by up to 1328 ULP on Q4_K, SURVEY.md section 0 finding 3.
 //
 // Shape of the work (HBM-bound byte unpack, no MFMA -- there is no contraction here):
-//   * unit of work = a GROUP of G consecutive blocks, owned by ONE wavefront (64 lanes);
-//   * the wave copies the group's packed bytes HBM -> VGPR -> its private LDS slice with
-//     coalesced 16 B/lane loads (a group starts 16-B aligned because 8*type_size % 16 == 0
-//     for every ggml block format);
-//   * every lane then produces CHUNKS of 8 consecutive output elements: it picks the quant
-//     bytes / scale fields it needs out of LDS (broadcast reads, natural alignment only),
-//     widens sub-byte fields with v_perm_b32 + the 0x6400 "1024+q" fp16 trick, applies the
-//     reference's rounding sequence in packed fp16, and issues ONE 16-byte store;
-//   * lane l of store s writes chunk 64*s + l, so each store instruction of the wave covers
-//     1 KiB of contiguous output (full 128-B lines, no partial-line writes);
-//   * waves never synchronise with each other (no __syncthreads, no atomics): LDS slices are
-//     wave-private, ordering inside a wave is in-order LDS issue + a compiler fence.
+//   * unit of work = a GROUP of G consecutive blocks, owned by a TEAM: one wavefront (default), or the
+//     2 / 4 wavefronts of a workgroup together (COOP; Q8_0, Q4_1, Q5_1);
+//   * the team copies the group's packed bytes HBM -> VGPR -> its LDS slice with coalesced
+//     16 B/lane loads (a group starts 16-B aligned because 8*type_size % 16 == 0 for every ggml
+//     block format);
+//   * every lane then produces CHUNKS of 8 consecutive output elements: a per-format DECODE picks
+//     the quant bytes / scale fields it needs out of LDS (broadcast reads, natural alignment only)
+//     and widens sub-byte fields with v_perm_b32; a generic ARITHMETIC stage applies the reference's
+//     rounding sequence; an OUTPUT stage converts and issues ONE 16-byte store;
+//   * lane l of store s writes unit TEAM*s + l, so each store instruction of a wave covers
+//     1 KiB of contiguous output (full 128-B lines, no partial-line writes) -- for fp32 output a
+//     lane owns 4 elements instead of 8 to keep it so;
+//   * teams never synchronise with each other (no atomics, no cross-workgroup state); inside a solo
+//     team ordering is in-order LDS issue + a compiler fence, inside a COOP team one s_barrier;
+//   * which workgroup takes which group is XCD-aware on large launches (Engine::run).
 //
 // No CUDA compatibility layer, no dual paths: this file is gfx950 code.
 #pragma once
@@ -652,7 +656,7 @@ struct Engine {
     }
 
     // DIRECT: no LDS staging -- every lane reads the few bytes its chunk needs straight from
-    // global memory (the same F::chunk code, pointed at the packed bytes).  A wave-row of 64 chunks
+    // global memory (the same F::fields decode, pointed at the packed bytes).  A wave-row of 64 chunks
     // touches 3-5 cache lines; neighbouring lanes share them through the vector L1.
     template <bool FULL>
     GGQ_DEV static void body_direct(const Work& w, int lane)

@@ -86,7 +86,7 @@ LEGACY_QTYPES = (Q.Q4_0, Q.Q4_1, Q.Q5_0, Q.Q5_1, Q.Q8_0)
 K_QTYPES = (Q.Q2_K, Q.Q3_K, Q.Q4_K, Q.Q5_K, Q.Q6_K)
 IQ_QTYPES = (Q.IQ4_NL, Q.IQ4_XS)
 
-# the formats with a hand-written HIP unpacker in csrc/ggq_kernels.hip
+# the formats with a hand-written HIP unpacker in csrc/ggq_device.hpp
 HIP_QTYPES = LEGACY_QTYPES + K_QTYPES + IQ_QTYPES
 
 
