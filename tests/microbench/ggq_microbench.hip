@@ -238,6 +238,40 @@ __global__ __launch_bounds__(W * 64) void k_fill_rows(ggq::u32x4* out, uint32_t 
         __builtin_nontemporal_store(ggq::u32x4{1, 2, (uint32_t)r, (uint32_t)t}, out + t * 256 + (wave * R + r) * 64 + lane);
 }
 
+// store cache-policy bits (gfx942/950: sc0, sc1, nt) on a pure fill, 4 waves x 1 row, run mapping 2^6
+template <int POL>
+__global__ __launch_bounds__(256) void k_fill_policy(ggq::u32x4* out, uint32_t xr)
+{
+    const uint64_t t = xmap(blockIdx.x, xr);
+    ggq::u32x4 v{1, 2, 3, (uint32_t)t};
+    ggq::u32x4* p = out + t * 256 + threadIdx.x;
+    if (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+    if (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+    if (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    if (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+    if (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(p), "v"(v) : "memory");
+    if (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(p), "v"(v) : "memory");
+    if (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+    if (POL == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" :: "v"(p), "v"(v) : "memory");
+}
+
+static void fill_policy()
+{
+    Timer T; double med, mn;
+    const uint64_t bytes = 6ull << 30;
+    ggq::u32x4* b;
+    HIP_CHECK(hipMalloc(&b, bytes));
+    const uint32_t grid = (uint32_t)(bytes / 4096);
+    const char* names[] = {"plain", "nt", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt", "sc0", "sc0 nt"};
+    for (int rep = 0; rep < 2; rep++) {
+#define POLICY(P) T.run([&] { k_fill_policy<P><<<grid, 256>>>(b, 6); }, 2, 9, med, mn); printf("FILLPOL %-11s %8.1f GB/s (median) %8.1f (best)\n", names[P], bytes / med / 1e6, bytes / mn / 1e6);
+        POLICY(0) POLICY(1) POLICY(2) POLICY(3) POLICY(4) POLICY(5) POLICY(6) POLICY(7)
+#undef POLICY
+        fflush(stdout);
+    }
+    HIP_CHECK(hipFree(b));
+}
+
 static void fill_rows()
 {
     Timer T; double med, mn;
@@ -697,10 +731,53 @@ static void ab_small_groups(const char* name, int qi)
     free_pool(P);
 }
 
-static void ab_coop_all()
+static void ab_coop_all()       // profiles/r01_microbench_o_coop_teams.txt
+{
+    printf("pool alignment %llu\n", (unsigned long long)pool_align());
+    for (int pairs : {64, 2}) {
+        const uint32_t xr = pairs == 64 ? 6 : 0;
+        ab_coop<ggq::FmtQ4_0, 64, true>("Q4_0", 0, pairs, xr);
+        ab_coop<ggq::FmtQ4_1, 64, true>("Q4_1", 1, pairs, xr);
+        ab_coop<ggq::FmtQ5_0, 64, true>("Q5_0", 2, pairs, xr);
+        ab_coop<ggq::FmtQ5_1, 64, true>("Q5_1", 3, pairs, 0);
+        ab_coop<ggq::FmtQ8_0, 64, true>("Q8_0", 4, pairs, xr);
+        ab_coop<ggq::FmtQ4_K, 8, true>("Q4_K", 7, pairs, xr);
+        ab_coop<ggq::FmtQ5_K, 8, true>("Q5_K", 8, pairs, xr);
+        ab_coop<ggq::FmtQ6_K, 8, false>("Q6_K", 9, pairs, xr);
+        ab_coop<ggq::FmtIQ4_NL, 64, true>("IQ4_NL", 10, pairs, xr);
+        ab_coop<ggq::FmtIQ4_XS, 8, true>("IQ4_XS", 11, pairs, xr);
+    }
+}
+
+static void ab_small_all()      // profiles/r01_microbench_p_q2k_q3k_shapes.txt
 {
     ab_small_groups<ggq::FmtQ2_K, false>("Q2_K", 5);
     ab_small_groups<ggq::FmtQ3_K, false>("Q3_K", 6);
+}
+
+static void ab_nt_all()         // non-temporal vs plain loads / stores under the run mapping (NT stores: +3.4 % on Q4_K)
+{
+    {
+        Pool P = make_pool(QTS[7], 64); AB ab;
+        ab_add<ggq::FmtQ4_K, 8, true, true, 1, 0, false, -1>(ab, "Q4_K", P, 0, 6);
+        ab_add<ggq::FmtQ4_K, 8, true, false, 1, 0, false, -1>(ab, "Q4_K", P, 0, 6);
+        ab_add<ggq::FmtQ4_K, 8, false, true, 1, 0, false, -1>(ab, "Q4_K", P, 0, 6);
+        ab_add<ggq::FmtQ4_K, 8, false, false, 1, 0, false, -1>(ab, "Q4_K", P, 0, 6);
+        ab.run(9, 3); free_pool(P);
+    }
+    {
+        Pool P = make_pool(QTS[4], 64); AB ab;
+        ab_add<ggq::FmtQ8_0, 128, true, true, 4, 0, false, -1, 1, true>(ab, "Q8_0", P, 0, 5);
+        ab_add<ggq::FmtQ8_0, 128, true, false, 4, 0, false, -1, 1, true>(ab, "Q8_0", P, 0, 5);
+        ab_add<ggq::FmtQ8_0, 128, false, true, 4, 0, false, -1, 1, true>(ab, "Q8_0", P, 0, 5);
+        ab.run(9, 3); free_pool(P);
+    }
+    {
+        Pool P = make_pool(QTS[9], 64); AB ab;
+        ab_add<ggq::FmtQ6_K, 8, false, true, 1, 0, false, -1>(ab, "Q6_K", P, 0, 6);
+        ab_add<ggq::FmtQ6_K, 8, false, false, 1, 0, false, -1>(ab, "Q6_K", P, 0, 6);
+        ab.run(9, 3); free_pool(P);
+    }
 }
 
 static void ab_xcd_all()
@@ -819,6 +896,9 @@ int main(int argc, char** argv)
     if (what == "abxcd") ab_xcd_all();
     if (what == "ceilx") ceilings_x();
     if (what == "abcoop") ab_coop_all();
+    if (what == "absmall") ab_small_all();
+    if (what == "abnt") ab_nt_all();
     if (what == "fillrows") fill_rows();
+    if (what == "fillpol") fill_policy();
     return rc ? 1 : 0;
 }
