@@ -85,7 +85,7 @@ thread_local int t_last_hip = 0;
 constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
-typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, hipStream_t);
+typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
 
 template <class F, int ARITH, int OUT>
 hipError_t run_one(const Desc& d, hipStream_t s)
@@ -99,14 +99,17 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     return hipGetLastError();
 }
 
+// The coarse index replaces the binary search only for the COOP teams: bench.py, alternating builds on one box, measured
+// Q4_1 +2.8 %, Q5_1 +1.3 %, Q8_0 +0.2 % with it and -0.4...-1.5 % for the solo formats (whose waves overlap the search with
+// each other's memory traffic anyway, and whose binary search mostly hits the scalar cache).
 template <class F, int ARITH, int OUT>
-hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, hipStream_t s)
+hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32_t* coarse, uint32_t coarse_shift, hipStream_t s)
 {
     using T = Tune<F>;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups));
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
     return hipGetLastError();
 }
 
@@ -161,6 +164,8 @@ struct Segment {
     int compute_dtype, out_dtype;
     uint32_t first, count;     // slice of the device table
     uint64_t groups;
+    uint64_t coarse_first;     // slice of the device coarse index (entries), and its granularity
+    uint32_t coarse_shift;
 };
 
 }  // namespace
@@ -168,6 +173,7 @@ struct Segment {
 struct ggq_plan {
     std::vector<Segment> segments;
     Desc* dev_table = nullptr;
+    uint32_t* dev_coarse = nullptr;    // per segment: entry holding group (c << shift), relative to the segment's first entry
     uint64_t bytes = 0;
     int device = 0;
 };
@@ -233,12 +239,13 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
     ggq_plan* plan = new (std::nothrow) ggq_plan();
     if (!plan) return GGQ_ERR_NOMEM;
     std::vector<Desc> table;
+    std::vector<uint32_t> coarse;
     try {
         table.reserve(n);
         for (int fi = 0; fi < N_FORMATS; fi++) {
             for (int cd_od = 0; cd_od < 9; cd_od++) {
                 const int cd = cd_od / 3, od = cd_od % 3;
-                Segment seg{&FORMATS[fi], cd, od, (uint32_t)table.size(), 0, 0};
+                Segment seg{&FORMATS[fi], cd, od, (uint32_t)table.size(), 0, 0, 0, 0};
                 for (uint32_t i = 0; i < n; i++) {
                     const ggq_desc& d = descs[i];
                     if (d.qtype != FORMATS[fi].qtype || d.compute_dtype != cd || d.out_dtype != od || d.n_blocks == 0) continue;
@@ -247,7 +254,20 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
                     seg.count++;
                     plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_F32 ? 4 : 2));
                 }
-                if (seg.count) plan->segments.push_back(seg);
+                if (seg.count) {
+                    // coarse index: at most 65536 entries per segment, at least 64 groups per entry
+                    seg.coarse_shift = 6;
+                    while ((seg.groups >> seg.coarse_shift) + 1 > 65536) seg.coarse_shift++;
+                    seg.coarse_first = coarse.size();
+                    const uint64_t entries = (seg.groups >> seg.coarse_shift) + 1;
+                    uint32_t idx = 0;
+                    for (uint64_t c = 0; c < entries; c++) {
+                        const uint64_t g0 = c << seg.coarse_shift;
+                        while (idx + 1 < seg.count && table[seg.first + idx + 1].first_group <= g0) idx++;
+                        coarse.push_back(idx);
+                    }
+                    plan->segments.push_back(seg);
+                }
             }
         }
     } catch (const std::bad_alloc&) {
@@ -258,7 +278,10 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
     if (!table.empty()) {
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&plan->dev_table), table.size() * sizeof(Desc));
         if (e == hipSuccess) e = hipMemcpy(plan->dev_table, table.data(), table.size() * sizeof(Desc), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&plan->dev_coarse), coarse.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(plan->dev_coarse, coarse.data(), coarse.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
+            if (plan->dev_coarse) (void)hipFree(plan->dev_coarse);
             if (plan->dev_table) (void)hipFree(plan->dev_table);
             delete plan;
             return e == hipErrorOutOfMemory ? GGQ_ERR_NOMEM : hip_fail(e);
@@ -272,7 +295,8 @@ int ggq_plan_launch(const ggq_plan* plan, void* hip_stream)
 {
     if (!plan) return GGQ_ERR_ARG;
     for (const Segment& seg : plan->segments) {
-        const hipError_t e = seg.fmt->many[seg.compute_dtype][seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, static_cast<hipStream_t>(hip_stream));
+        const hipError_t e = seg.fmt->many[seg.compute_dtype][seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, plan->dev_coarse + seg.coarse_first,
+                                                                               seg.coarse_shift, static_cast<hipStream_t>(hip_stream));
         if (e != hipSuccess) return hip_fail(e);
     }
     return GGQ_OK;
@@ -284,6 +308,7 @@ uint32_t ggq_plan_kernels(const ggq_plan* plan) { return plan ? (uint32_t)plan->
 void ggq_plan_destroy(ggq_plan* plan)
 {
     if (!plan) return;
+    if (plan->dev_coarse) (void)hipFree(plan->dev_coarse);
     if (plan->dev_table) (void)hipFree(plan->dev_table);
     delete plan;
 }

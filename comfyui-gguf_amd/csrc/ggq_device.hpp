@@ -735,15 +735,25 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total
     Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
-// many tensors of one format: table in device memory, sorted by first_group
+// many tensors of one format: table in device memory, sorted by first_group.  Finding the tensor of group g is a chain
+// of DEPENDENT scalar loads at the head of every wave: `coarse[c]` (optional) = the entry that holds group c << coarse_shift,
+// which leaves a 1-2 step forward scan instead of a log2(n)-step binary search -- a team holds its wave slots idle during
+// that chain, which costs the multi-wave (COOP) teams most (tests/microbench `ablocate`).
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
-__global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2)
+__global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2,
+                                                           const uint32_t* __restrict__ coarse, uint32_t coarse_shift)
 {
     Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
-        uint32_t lo = 0, hi = n;                        // last entry with first_group <= g
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (table[mid].first_group <= g) lo = mid; else hi = mid;
+        uint32_t lo = 0;                                // last entry with first_group <= g
+        if (coarse != nullptr) {
+            lo = coarse[g >> coarse_shift];
+            while (lo + 1 < n && table[lo + 1].first_group <= g) lo++;
+        } else {
+            uint32_t hi = n;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (table[mid].first_group <= g) lo = mid; else hi = mid;
+            }
         }
         const Desc d = table[lo];
         return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};

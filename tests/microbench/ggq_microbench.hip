@@ -423,7 +423,7 @@ static void time_variant(const char* name, Pool& P, Timer& T)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     double med, mn;
-    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u); }, 3, 31, med, mn);
+    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u); }, 3, 31, med, mn);
     const double bytes = (double)P.elements * (2.0 + (double)P.ts / P.bs);
     printf("VAR %-6s %s thr=%-2d G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, DIRECT ? "direct" : "lds   ", THR, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
            (unsigned long long)blocks, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6, ok ? "ok" : "MISMATCH");
@@ -544,7 +544,7 @@ static void launch3(Pool& P)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u);
+        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipFree(dt));
 }
@@ -618,7 +618,7 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
     char buf[160];
     snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, COOP ? "coop" : (DIRECT ? "direct" : "lds"), G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun, THR, dyn_lds / 1024);
     if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
-    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun); },
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun, nullptr, 0u); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R, COOP>()});
 }
 
@@ -747,6 +747,26 @@ static void ab_coop_all()       // profiles/r01_microbench_o_coop_teams.txt
         ab_coop<ggq::FmtIQ4_NL, 64, true>("IQ4_NL", 10, pairs, xr);
         ab_coop<ggq::FmtIQ4_XS, 8, true>("IQ4_XS", 11, pairs, xr);
     }
+}
+
+// how much does finding the tensor cost?  the same Q4_K pool as 128 descriptors (7-step binary search per wave) and as ONE
+// descriptor covering the whole (contiguous) pool (no search)
+static void ab_locate()
+{
+    Pool P = make_pool(QTS[7], 64);
+    Pool M = P;                                  // shares the device buffers
+    uint64_t nb = 0;
+    for (auto& d : P.descs) nb += d.n_blocks;
+    M.descs.assign(1, ggq::Desc{P.descs[0].packed, P.descs[0].out, nb, 0});
+    AB ab;
+    ab_add<ggq::FmtQ4_K, 8, true, true, 1, 0, false, -1>(ab, "Q4_K table128", P, 0, 6);
+    ab_add<ggq::FmtQ4_K, 8, true, true, 1, 0, false, -1>(ab, "Q4_K merged1", M, 0, 6);
+    ab_add<ggq::FmtQ4_K, 8, true, true, 4, 0, false, -1, 1, true>(ab, "Q4_K table128", P, 0, 6);
+    ab_add<ggq::FmtQ4_K, 8, true, true, 4, 0, false, -1, 1, true>(ab, "Q4_K merged1", M, 0, 6);
+    ab_add<ggq::FmtQ4_K, 8, true, true, 2, 0, false, -1, 1, true>(ab, "Q4_K table128", P, 0, 6);
+    ab_add<ggq::FmtQ4_K, 8, true, true, 2, 0, false, -1, 1, true>(ab, "Q4_K merged1", M, 0, 6);
+    ab.run(9, 3);
+    free_pool(P);
 }
 
 static void ab_small_all()      // profiles/r01_microbench_p_q2k_q3k_shapes.txt
@@ -898,6 +918,7 @@ int main(int argc, char** argv)
     if (what == "abcoop") ab_coop_all();
     if (what == "absmall") ab_small_all();
     if (what == "abnt") ab_nt_all();
+    if (what == "ablocate") ab_locate();
     if (what == "fillrows") fill_rows();
     if (what == "fillpol") fill_policy();
     return rc ? 1 : 0;
