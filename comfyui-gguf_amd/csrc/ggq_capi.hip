@@ -34,6 +34,14 @@ using namespace ggq;
 //     launches below XRUN_MIN_ELEMENTS keep the identity mapping too.  Shorter runs lose 5-10 %.
 // The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
 // artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
+// LDS_PAD: untouched dynamic LDS added to every launch of a format -- it only caps how many teams a CU holds at once.
+// Fewer resident teams help three formats (bench.py, alternating settings on one box); the others are flat up to 4 KiB
+// and lose beyond (Q2_K / Q3_K -10 % at 8 KiB).  GGQ_LDS_PAD=<bytes> (environment, read once) forces one value for every
+// format: a measurement knob.
+template <class F> struct PadOf { static constexpr uint32_t V = 0; };
+template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };   // 26 teams / CU: +3.6...5 %
+template <> struct PadOf<FmtQ5_0> { static constexpr uint32_t V = 8192; };   // 16 teams / CU: +2.1 %
+template <> struct PadOf<FmtQ5_K> { static constexpr uint32_t V = 8192; };   // 16 teams / CU: +1.5 %
 template <class F> struct Tune {                 // default: solo teams, NT loads, runs of 64 groups
     static constexpr int G = (F::BS == 256) ? 8 : 64;
     static constexpr bool COOP = false, NTL = true, NTS = true;
@@ -74,6 +82,20 @@ int xrun_override()
     return v;
 }
 
+int env_int(const char* name, int lo, int hi)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return -1;
+    const int x = atoi(e);
+    return (x >= lo && x <= hi) ? x : -1;
+}
+
+template <class F> uint32_t lds_pad_for()
+{
+    static const int o = env_int("GGQ_LDS_PAD", 0, 64 * 1024);
+    return o >= 0 ? (uint32_t)o : PadOf<F>::V;
+}
+
 template <class F> uint32_t xrun_for(uint64_t groups)
 {
     const int o = xrun_override();
@@ -95,7 +117,7 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, d, groups, xrun_for<F>(groups));
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_for<F>(groups));
     return hipGetLastError();
 }
 
@@ -109,7 +131,7 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), 0, s, table, n, groups, xrun_for<F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_for<F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
     return hipGetLastError();
 }
 

@@ -680,6 +680,7 @@ struct Engine {
     template <class Locate>
     GGQ_DEV static void run(uint64_t total_groups, uint32_t xrun_log2, Locate locate)
     {
+        // (the host may add untouched DYNAMIC LDS to a launch: it only caps how many workgroups a CU holds at once)
         __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : (COOP ? 1 : WAVES) * SLICE];
         const int wave = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int lane = COOP ? (int)threadIdx.x : (int)(threadIdx.x & 63);

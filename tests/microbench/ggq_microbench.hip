@@ -769,6 +769,24 @@ static void ab_locate()
     free_pool(P);
 }
 
+// resident waves per CU, capped by an untouched dynamic-LDS allocation (160 KiB per CU / (static slice + dyn) workgroups)
+template <class F, int G, bool NTL>
+static void ab_occ1(const char* name, int qi, uint32_t xr)
+{
+    Pool P = make_pool(QTS[qi], 64);
+    AB ab;
+    for (int kb : {0, 2, 3, 4, 5, 6, 8, 12, 18})
+        ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P, kb * 1024, xr);
+    ab.run(9, 3);
+    free_pool(P);
+}
+static void ab_occ1_all()
+{
+    ab_occ1<ggq::FmtQ4_K, 8, true>("Q4_K", 7, 6);
+    ab_occ1<ggq::FmtQ2_K, 8, false>("Q2_K", 5, 0);
+    ab_occ1<ggq::FmtQ6_K, 8, false>("Q6_K", 9, 6);
+}
+
 static void ab_small_all()      // profiles/r01_microbench_p_q2k_q3k_shapes.txt
 {
     ab_small_groups<ggq::FmtQ2_K, false>("Q2_K", 5);
@@ -919,6 +937,7 @@ int main(int argc, char** argv)
     if (what == "absmall") ab_small_all();
     if (what == "abnt") ab_nt_all();
     if (what == "ablocate") ab_locate();
+    if (what == "abocc") ab_occ1_all();
     if (what == "fillrows") fill_rows();
     if (what == "fillpol") fill_policy();
     return rc ? 1 : 0;
