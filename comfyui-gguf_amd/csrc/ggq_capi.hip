@@ -35,13 +35,13 @@ using namespace ggq;
 // The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
 // artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
 // LDS_PAD: untouched dynamic LDS added to every launch of a format -- it only caps how many teams a CU holds at once.
-// Fewer resident teams help three formats (bench.py, alternating settings on one box); the others are flat up to 4 KiB
-// and lose beyond (Q2_K / Q3_K -10 % at 8 KiB).  GGQ_LDS_PAD=<bytes> (environment, read once) forces one value for every
+// Fewer resident teams help two formats in every condition tried (bench.py headline pool and per-format table, two boxes,
+// alternating settings); Q5_K gained 1.3 % as the headline pool but lost 4 % in the per-format table, so it has no pad;
+// the others are flat up to 4 KiB and lose beyond (Q2_K / Q3_K -10 % at 8 KiB).  GGQ_LDS_PAD=<bytes> (environment, read once) forces one value for every
 // format: a measurement knob.
 template <class F> struct PadOf { static constexpr uint32_t V = 0; };
 template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };   // 26 teams / CU: +3.6...5 %
 template <> struct PadOf<FmtQ5_0> { static constexpr uint32_t V = 8192; };   // 16 teams / CU: +2.1 %
-template <> struct PadOf<FmtQ5_K> { static constexpr uint32_t V = 8192; };   // 16 teams / CU: +1.5 %
 template <class F> struct Tune {                 // default: solo teams, NT loads, runs of 64 groups
     static constexpr int G = (F::BS == 256) ? 8 : 64;
     static constexpr bool COOP = false, NTL = true, NTS = true;
