@@ -5,6 +5,7 @@
 #include "../../include/ggq_gguf.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <new>
 #include <vector>
 #include <algorithm>
@@ -13,41 +14,50 @@ namespace {
 
 using namespace ggq;
 
-// Launch geometry, chosen by interleaved A/B runs on MI355X over pools whose PACKED bytes alone are
-// 4-12x the 256 MiB Infinity Cache (DESIGN.md section 4 "Tuning", profiles/r01_microbench_*):
-//   * TEAM: who owns a group.  "solo" = one wavefront owns 2048 output elements from first load to last store, one
-//     wave per workgroup (0.5-4 % better than four independent waves).  "coop" = the 4 waves of a workgroup own 4096
-//     elements together (one shared LDS slice, one s_barrier): the load is spread over 256 threads and every wave
-//     stores 2 rows instead of 4 back to back.  Shipped where BOTH the torch-free harness and bench.py (same box,
-//     alternating builds) agree: Q8_0 +6.2 % (the format with the most packed bytes per group: 2176 B), Q4_1 +1.6 %,
-//     Q5_1 +1.2 % as 2 waves x 2048 elements.  The harness also showed Q6_K +5.5 %, Q5_K +3.5 %, Q5_0 +3.4 %
-//     (profiles/r01_microbench_o_coop_teams.txt) but bench.py, whose tensors are separate 2 MiB-aligned allocations,
-//     measured -0.4 %, -3.5 %, -0.9 % for them, so they stay solo, as do the 4-bit formats (+-0.7 % either way) and
-//     Q2_K / Q3_K (-4...-6 % with any coop shape).  One row per wave (4 waves x 2048) halves the rate: the per-wave
-//     fixed cost dominates.
-//   * non-temporal stores (+3-4 %); non-temporal loads are a wash for the 4/5/8-bit formats and cost
-//     2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
+// Launch geometry.  Every choice below comes from alternating two settings on ONE MI355X box (box-to-box spread is +-3 %):
+// the torch-free harness (tests/microbench, profiles/r01_microbench_*) proposes, bench.py -- as the headline pool AND
+// inside its per-format table, whose tensors are separate 2 MiB-aligned torch allocations -- decides.  Pools: 3 G
+// elements per format, packed bytes alone 4-12x the 256 MiB Infinity Cache.
+//   * TEAM: who owns a group.  "coop" (default) = the 4 waves of a workgroup own 4096 output elements together: one
+//     shared LDS slice, the load spread over 256 threads, one s_barrier, every wave stores 2 rows of 1 KiB (pure fills run
+//     6 % faster with fewer rows per wave).  "solo" = one wavefront owns 2048 elements from first load to last store, one
+//     wave per workgroup.  Coop vs solo at bench.py level (headline / per-format table): Q8_0 +6.3 %, Q5_0 +1.2 / +3.7 %,
+//     Q5_K +3.3 / +0.7 %, IQ4_XS +3.2 / +1.3 %, Q4_1 +2.0 %, Q4_0 +0.6 / +3.7 %, IQ4_NL +1.4 / +1.1 %, Q4_K +0.4 / +1.5 %;
+//     Q5_1 does best as 2 waves x 2048 elements (+1.7 %); Q6_K is level with its occupancy-capped solo shape and keeps it;
+//     Q2_K / Q3_K lose 4-7 % with any coop shape and stay solo.  One row per wave (4 waves x 2048) halves the rate -- the
+//     per-wave fixed cost dominates -- and a team holds its wave slots idle while it finds its tensor, which is why the
+//     coop teams get the coarse index (run_many below): before it, coop LOST up to 3.5 % on Q5_K / Q5_0 / Q6_K.
+//   * non-temporal stores (+3.4 %; the other cache-policy bits make no difference); non-temporal loads are a wash for
+//     the 4/5/8-bit formats and cost 2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
 //   * XCD-aware workgroup -> group mapping on LARGE launches (profiles/r01_microbench_l_xcd_run_mapping.txt): inside each
 //     tile every XCD takes a run of consecutive groups covering 256 KiB of fp16 output (64 solo groups, 32 coop groups)
-//     instead of every eighth group.  Interleaved A/B on 3 G-element pools: +1...+5 % for the 4/5/6/8-bit formats, -4 %
-//     for Q2_K / Q3_K and -1.5 % for Q5_1 (those keep the identity mapping); on 47 M-element launches it costs 1-3 %, so
-//     launches below XRUN_MIN_ELEMENTS keep the identity mapping too.  Shorter runs lose 5-10 %.
-// The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark
-// artefact: 89 % on a 186 MB Q2_K pool, 60 % on a 990 MB one) and is not used.
-// LDS_PAD: untouched dynamic LDS added to every launch of a format -- it only caps how many teams a CU holds at once.
-// Fewer resident teams help two formats in every condition tried (bench.py headline pool and per-format table, two boxes,
-// alternating settings); Q5_K gained 1.3 % as the headline pool but lost 4 % in the per-format table, so it has no pad;
-// the others are flat up to 4 KiB and lose beyond (Q2_K / Q3_K -10 % at 8 KiB).  GGQ_LDS_PAD=<bytes> (environment, read once) forces one value for every
-// format: a measurement knob.
+//     instead of every eighth group: +1.2...+2.2 % at bench.py level; -4 % for Q2_K / Q3_K and -1.5 % for Q5_1 (identity
+//     mapping for those); on 47 M-element launches it costs 1-3 %, so launches below XRUN_MIN_ELEMENTS keep the identity
+//     mapping too.  Shorter runs lose 5-10 %; rotating an XCD's slot from tile to tile loses 10 %.
+//   * LDS_PAD: untouched dynamic LDS added to a format's launches -- it only caps how many teams a CU holds at once.
+//     Q6_K (solo) runs 4.2 % faster at 26 teams per CU; the other formats are flat up to 4 KiB and lose beyond.
+// The no-LDS DIRECT engine only wins when the packed pool fits the Infinity Cache (a benchmark artefact) and is not used.
+// Measurement knobs (environment, read once): GGQ_XRUN_LOG2, GGQ_LDS_PAD force one value for every format.
 template <class F> struct PadOf { static constexpr uint32_t V = 0; };
-template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };   // 26 teams / CU: +3.6...5 %
-template <> struct PadOf<FmtQ5_0> { static constexpr uint32_t V = 8192; };   // 16 teams / CU: +2.1 %
-template <class F> struct Tune {                 // default: solo teams, NT loads, runs of 64 groups
+template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };
+template <class F> struct TuneSolo {             // one-wave teams x 2048 elements, NT loads, runs of 64 groups
     static constexpr int G = (F::BS == 256) ? 8 : 64;
     static constexpr bool COOP = false, NTL = true, NTS = true;
     static constexpr int WAVES = 1;
     static constexpr uint32_t XRUN_LOG2 = 6;
 };
+template <class F> struct TuneCoop {             // teams of 4 waves x 4096 elements, NT loads, runs of 32 groups
+    static constexpr int G = (F::BS == 256) ? 16 : 128;
+    static constexpr bool COOP = true, NTL = true, NTS = true;
+    static constexpr int WAVES = 4;
+    static constexpr uint32_t XRUN_LOG2 = 5;
+};
+// Tune<F> = the shape for the stock fp16 arithmetic (every output dtype); TuneFor<F, ARITH> below picks per mode.
+#ifdef GGQ_SOLO_ONLY      /* A/B builds only: one-wave teams for every format */
+template <class F> struct Tune : TuneSolo<F> {};
+#else
+template <class F> struct Tune : TuneCoop<F> {};
+#endif
 #define GGQ_TUNE(F, G_, COOP_, WAVES_, NTL_, XRUN_)                                              \
     template <> struct Tune<F> {                                                                 \
         static constexpr int G = G_, WAVES = WAVES_;                                             \
@@ -58,14 +68,17 @@ template <class F> struct Tune {                 // default: solo teams, NT load
 GGQ_TUNE(FmtQ2_K,    8,  false, 1,    false,    0);
 GGQ_TUNE(FmtQ3_K,    8,  false, 1,    false,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
-#ifdef GGQ_SOLO_ONLY    /* A/B builds only: every format on solo teams, as before the coop engine */
-GGQ_TUNE(FmtQ5_1,   64,  false, 1,    true,     0);
-#else
-GGQ_TUNE(FmtQ8_0,  128,  true,  4,    true,     5);
-GGQ_TUNE(FmtQ4_1,  128,  true,  4,    true,     5);
 GGQ_TUNE(FmtQ5_1,   64,  true,  2,    true,     0);
-#endif
 #undef GGQ_TUNE
+
+// The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
+// two chunks per thread the coop teams then lose 1-7 % on every format but the two with the lightest arithmetic per
+// packed byte (bench.py per-mode table, solo vs coop builds on one box): those modes run the solo shape.
+template <class F> struct CoopInAllModes { static constexpr bool V = false; };
+template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };     // +7...12 % in every mode
+template <> struct CoopInAllModes<FmtQ4_1> { static constexpr bool V = true; };     // +4 % fp32 arithmetic, level in bf16
+template <class F, int ARITH> struct TuneFor
+    : std::conditional<ARITH == AR_F16 || !Tune<F>::COOP || CoopInAllModes<F>::V || Tune<F>::WAVES != 4, Tune<F>, TuneSolo<F>>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 
@@ -96,11 +109,12 @@ template <class F> uint32_t lds_pad_for()
     return o >= 0 ? (uint32_t)o : PadOf<F>::V;
 }
 
-template <class F> uint32_t xrun_for(uint64_t groups)
+template <class F, int ARITH> uint32_t xrun_for(uint64_t groups)
 {
+    using T = TuneFor<F, ARITH>;
     const int o = xrun_override();
     if (o >= 0) return (uint32_t)o;
-    return groups * (uint64_t)(Tune<F>::G * F::BS) >= XRUN_MIN_ELEMENTS ? Tune<F>::XRUN_LOG2 : 0u;
+    return groups * (uint64_t)(T::G * F::BS) >= XRUN_MIN_ELEMENTS ? T::XRUN_LOG2 : 0u;
 }
 
 thread_local int t_last_hip = 0;
@@ -112,12 +126,12 @@ typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, 
 template <class F, int ARITH, int OUT>
 hipError_t run_one(const Desc& d, hipStream_t s)
 {
-    using T = Tune<F>;
+    using T = TuneFor<F, ARITH>;
     const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_for<F>(groups));
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_for<F, ARITH>(groups));
     return hipGetLastError();
 }
 
@@ -127,16 +141,17 @@ hipError_t run_one(const Desc& d, hipStream_t s)
 template <class F, int ARITH, int OUT>
 hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32_t* coarse, uint32_t coarse_shift, hipStream_t s)
 {
-    using T = Tune<F>;
+    using T = TuneFor<F, ARITH>;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_for<F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_for<F, ARITH>(groups), T::COOP ? coarse : nullptr, coarse_shift);
     return hipGetLastError();
 }
 
 struct FormatEntry {
-    int qtype, block_size, type_size, group;
+    int qtype, block_size, type_size;
+    int group[3];          // blocks per group, by compute dtype (the team shape may differ per arithmetic mode)
     one_fn one[3][3];      // [compute dtype][out dtype]
     many_fn many[3][3];
 };
@@ -144,7 +159,7 @@ struct FormatEntry {
 #define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
 #define GGQ_FORMAT(F)                                                                          \
     FormatEntry {                                                                              \
-        F::ID, F::BS, F::TS, Tune<F>::G,                                                       \
+        F::ID, F::BS, F::TS, {TuneFor<F, AR_F16>::G, TuneFor<F, AR_BF16>::G, TuneFor<F, AR_F32>::G},     \
         {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
         {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)}    \
     }
@@ -272,7 +287,7 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
                     const ggq_desc& d = descs[i];
                     if (d.qtype != FORMATS[fi].qtype || d.compute_dtype != cd || d.out_dtype != od || d.n_blocks == 0) continue;
                     table.push_back(Desc{static_cast<const uint8_t*>(d.packed), static_cast<uint8_t*>(d.out), d.n_blocks, seg.groups});
-                    seg.groups += (d.n_blocks + FORMATS[fi].group - 1) / FORMATS[fi].group;
+                    seg.groups += (d.n_blocks + FORMATS[fi].group[cd] - 1) / FORMATS[fi].group[cd];
                     seg.count++;
                     plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_F32 ? 4 : 2));
                 }
