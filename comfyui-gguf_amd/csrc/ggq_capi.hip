@@ -123,16 +123,33 @@ constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
 
-template <class F, int ARITH, int OUT>
-hipError_t run_one(const Desc& d, hipStream_t s)
+// Single tensors of layer size (per-layer calls, ops.py:177; rocprof kernel times of 3072x3072 / 3072x12288 tensors, solo vs coop
+// builds): the coop shape is 3-8 % FASTER for the 4/5-bit formats (Q4_K 6.10 vs 6.61 us, 17.7 vs 18.1 us) but 3-8 % SLOWER for
+// Q8_0 (6.52 vs 6.03 us, 20.6 vs 20.0 us), whose coop win only shows on whole-model launches: Q8_0 tensors below
+// XRUN_MIN_ELEMENTS take the solo shape.
+template <class F> struct SoloWhenSmall { static constexpr bool V = false; };
+template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
+
+template <class T, class F, int ARITH, int OUT>
+hipError_t launch_one(const Desc& d, hipStream_t s)
 {
-    using T = TuneFor<F, ARITH>;
     const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_for<F, ARITH>(groups));
+    const int o = xrun_override();
+    const uint32_t xrun = o >= 0 ? (uint32_t)o : (groups * (uint64_t)(T::G * F::BS) >= XRUN_MIN_ELEMENTS ? T::XRUN_LOG2 : 0u);
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun);
     return hipGetLastError();
+}
+
+template <class F, int ARITH, int OUT>
+hipError_t run_one(const Desc& d, hipStream_t s)
+{
+    if constexpr (SoloWhenSmall<F>::V && TuneFor<F, ARITH>::COOP) {
+        if (d.n_blocks * (uint64_t)F::BS < XRUN_MIN_ELEMENTS) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
+    }
+    return launch_one<TuneFor<F, ARITH>, F, ARITH, OUT>(d, s);
 }
 
 // The coarse index replaces the binary search only for the COOP teams: bench.py, alternating builds on one box, measured

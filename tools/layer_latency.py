@@ -18,12 +18,13 @@ def main():
     qt = pkg.qtypes
     dev = torch.device("cuda:0")
     out = {}
+    cols = int(os.environ.get("GGQ_LAYER_COLS", "3072"))       # 3072 = FLUX shape B, 12288 = shape C
     for qname in (sys.argv[1:] or ["Q4_K", "Q8_0", "Q6_K"]):
         q = qt.Q[qname]
         bs, ts = qt.block_geometry(q)
-        n_blocks = 3072 * 3072 // bs
-        pool = [pkg.ops.GGMLTensor(torch.randint(0, 256, (n_blocks * ts,), dtype=torch.uint8, device=dev), tensor_type=q, tensor_shape=(3072, 3072))
-                for _ in range(64)]
+        n_blocks = 3072 * cols // bs
+        pool = [pkg.ops.GGMLTensor(torch.randint(0, 256, (n_blocks * ts,), dtype=torch.uint8, device=dev), tensor_type=q, tensor_shape=(3072, cols))
+                for _ in range(64 if cols <= 3072 else 24)]
         for dtype in (torch.float16, torch.bfloat16):
             for _ in range(2):
                 for t in pool:
@@ -38,7 +39,7 @@ def main():
             torch.cuda.synchronize()
             t_all = time.perf_counter() - t0
             n = reps * len(pool)
-            nbytes = qt.algorithmic_bytes(q, 3072 * 3072)
+            nbytes = qt.algorithmic_bytes(q, 3072 * cols)
             out[f"{qname}->{str(dtype).split('.')[-1]}"] = {"host_us_per_call": round(t_host / n * 1e6, 2), "e2e_us_per_call": round(t_all / n * 1e6, 2),
                                                             "e2e_GBps": round(nbytes * n / t_all / 1e9, 1)}
     import json
