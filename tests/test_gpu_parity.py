@@ -69,11 +69,12 @@ def test_golden_vectors(pkg, golden_dir, name):
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("mode", ["nominal", "adversarial"])
 def test_against_oracle_ragged_sizes(pkg, name, mode):
-    """Every group-boundary case: 1 block, G-1, G, G+1, several groups + a ragged tail."""
+    """Every group-boundary case of both team shapes (one-wave teams own G blocks, workgroup teams 2G): 1 block,
+    G-1, G, G+1, 2G-1, 2G, 2G+1, several groups + a ragged tail."""
     q = pkg.qtypes.Q[name]
     bs, ts = pkg.qtypes.block_geometry(q)
     G = 64 if bs == 32 else 8
-    for n in (1, G - 1, G, G + 1, 5 * G + 3, 1031 if bs == 256 else 9001):
+    for n in (1, G - 1, G, G + 1, 2 * G - 1, 2 * G, 2 * G + 1, 5 * G + 3, 6 * G, 1031 if bs == 256 else 9001):
         blocks = pkg.synth.make_blocks(q, n, seed=n, mode=mode)
         want = oracle.dequant_f16(q, blocks)
         t = _carrier(pkg, blocks, q)
@@ -129,7 +130,7 @@ def test_dequant_tensor_all_dtype_combinations(pkg, name, mode):
     q = pkg.qtypes.Q[name]
     bs, _ = pkg.qtypes.block_geometry(q)
     G = 64 if bs == 32 else 8
-    for n in (1, G + 1, 7 * G + 5):
+    for n in (1, G + 1, 2 * G, 7 * G + 5):
         blocks = pkg.synth.make_blocks(q, n, seed=1000 + n, mode=mode)
         t = _carrier(pkg, blocks, q)
         for compute in ("f16", "bf16", "f32"):
