@@ -39,6 +39,17 @@ class GGMLTensor(torch.Tensor):
     def detach(self, *args, **kwargs):
         return self
 
+    def copy_(self, *args, **kwargs):              # ops.py:70-75: a failing in-place copy is logged, not raised
+        try:
+            return super().copy_(*args, **kwargs)
+        except Exception as e:                     # noqa: BLE001 -- the reference swallows everything here
+            import logging
+            logging.warning(f"ignoring 'copy_' on tensor: {e}")
+
+    def new_empty(self, size, *args, **kwargs):    # ops.py:77-85: same type and attrs, logical shape = the new size
+        return GGMLTensor(super().new_empty(size, *args, **kwargs), tensor_type=getattr(self, "tensor_type", None),
+                          tensor_shape=size, patches=getattr(self, "patches", []))
+
     @property
     def shape(self):                               # ops.py:87-91: the LOGICAL shape
         return getattr(self, "tensor_shape", self.size())

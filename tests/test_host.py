@@ -174,6 +174,10 @@ def test_ggml_tensor_carries_attrs(pkg):
     assert isinstance(u, T) and u.tensor_type == Q.Q4_K and u.shape == torch.Size((2, 256))
     assert t.clone() is t and t.detach() is t
     assert pkg.dequant.is_quantized(t)
+    e = t.new_empty((7,))
+    assert isinstance(e, T) and e.tensor_type == Q.Q4_K and e.shape == torch.Size((7,)) and e.size() == torch.Size((7,))
+    assert t.copy_(torch.zeros(288, dtype=torch.uint8)) is not None
+    assert t.copy_(torch.zeros(5, dtype=torch.uint8)) is None          # shape mismatch: logged and ignored (ops.py:70-75)
 
 
 def test_partition_covers_and_balances(pkg):
