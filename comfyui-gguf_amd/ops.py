@@ -1,12 +1,13 @@
-"""The two boundary types the hot path is called through, in the smallest form that needs no
-ComfyUI import: ``GGMLTensor`` (reference ops.py:44-91) and the ``get_weight`` -> ``F.linear``
-call chain of ``GGMLOps.Linear`` (reference ops.py:166-191, 242-244).
+"""The boundary types the hot path is called through, in the smallest form that needs no
+ComfyUI import: ``GGMLTensor`` (reference ops.py:44-91), the ``get_weight`` / ``cast_bias_weight``
+call chain of ``GGMLLayer`` (reference ops.py:166-211) and the five layer types that call it
+(``GGMLOps.Linear / Conv2d / Embedding / LayerNorm / GroupNorm``, reference ops.py:227-271).
 
 In a real ComfyUI install the reference's own classes stay in place (they are "reused as-is",
 SURVEY.md section 2 rows 7-8) and only the dequant functions underneath them are replaced by
 install.py.  These stand-ins exist so the path can be driven end to end -- tests, smoke, bench --
 on a machine that has neither ComfyUI nor the reference checked out (the GPU box).  LoRA patches,
-state-dict hooks and the other layer types belong to the reference's control plane and are not
+state-dict hooks and VRAM accounting belong to the reference's control plane and are not
 re-implemented here.
 """
 import torch
@@ -55,33 +56,105 @@ class GGMLTensor(torch.Tensor):
         return getattr(self, "tensor_shape", self.size())
 
 
-class GGMLLinear(torch.nn.Module):
-    """``GGMLOps.Linear`` reduced to the hot path: every forward re-dequantizes the weight
-    (no caching, ops.py:166-191) on the device the packed bytes live on, then ``F.linear``."""
+class GGMLLayer(torch.nn.Module):
+    """What the reference's ``GGMLLayer`` does on the hot path (ops.py:93-211): keep the packed weight / bias, and on
+    every forward re-dequantize them (no caching, ops.py:166-191) on the device the input lives on.  LoRA patches,
+    state-dict hooks and VRAM accounting are the reference's control plane and are not restated."""
 
-    dequant_dtype = None                           # GGMLLayer.dequant_dtype, ops.py:98
+    dequant_dtype = None                           # ops.py:98; set by the loader nodes (nodes.py:152-157)
 
     def __init__(self, weight, bias=None):
         super().__init__()
         self.weight = weight
         self.bias = bias
 
+    def is_ggml_quantized(self):                   # ops.py:103-108
+        return is_quantized(self.weight) or is_quantized(self.bias)
+
     def get_weight(self, tensor, dtype):           # ops.py:166-181 without the LoRA branch
         if tensor is None:
             return None
         weight = dequantize_tensor(tensor, dtype, self.dequant_dtype)
-        if isinstance(weight, GGMLTensor):
+        if isinstance(weight, GGMLTensor):         # ops.py:180-181: never hand the subclass on
             weight = weight.as_subclass(torch.Tensor)
         return weight
 
-    def cast_bias_weight(self, input):             # ops.py:194-211
-        device, dtype = input.device, input.dtype
-        bias = self.get_weight(self.bias.to(device), dtype) if self.bias is not None else None
+    def cast_bias_weight(self, input=None, dtype=None, device=None, bias_dtype=None):   # ops.py:194-211
+        if input is not None:
+            if dtype is None:
+                dtype = getattr(input, "dtype", torch.float32)
+            if bias_dtype is None:
+                bias_dtype = dtype
+            if device is None:
+                device = input.device
+        bias = None
+        if self.bias is not None:
+            bias = self.get_weight(self.bias.to(device), dtype)
+            bias = bias.to(device=device, dtype=bias_dtype)
         weight = self.get_weight(self.weight.to(device), dtype)
+        weight = weight.to(device=device, dtype=dtype)
         return weight, bias
 
-    def forward(self, input):                      # ops.py:242-244
-        if not (is_quantized(self.weight) or is_quantized(self.bias)):
+
+class GGMLLinear(GGMLLayer):
+    """``GGMLOps.Linear`` (ops.py:227-244)."""
+
+    def forward(self, input):
+        if not self.is_ggml_quantized():
             return torch.nn.functional.linear(input, self.weight.to(input.dtype), None if self.bias is None else self.bias.to(input.dtype))
         weight, bias = self.cast_bias_weight(input)
         return torch.nn.functional.linear(input, weight, bias)
+
+
+class GGMLEmbedding(GGMLLayer):
+    """``GGMLOps.Embedding`` (ops.py:251-260): the (possibly quantized) table is dequantized whole, then indexed.  As in the
+    reference, a table stored in fp16 / bf16 is used in its own dtype and the result cast to ``out_dtype``."""
+
+    def __init__(self, weight, padding_idx=None):
+        super().__init__(weight, None)
+        self.padding_idx = padding_idx
+
+    def forward(self, input, out_dtype=None):
+        output_dtype = out_dtype
+        if self.weight.dtype == torch.float16 or self.weight.dtype == torch.bfloat16:
+            out_dtype = None
+        weight, _ = self.cast_bias_weight(self, device=input.device, dtype=out_dtype)
+        return torch.nn.functional.embedding(input, weight, self.padding_idx).to(dtype=output_dtype)
+
+
+class GGMLConv2d(GGMLLayer):
+    """``GGMLOps.Conv2d`` (ops.py:246-249); the packed weight's logical shape is (out, in, kh, kw)."""
+
+    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+        super().__init__(weight, bias)
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+
+    def forward(self, input):
+        weight, bias = self.cast_bias_weight(input)
+        return torch.nn.functional.conv2d(input, weight, bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class GGMLLayerNorm(GGMLLayer):
+    """``GGMLOps.LayerNorm`` (ops.py:262-266)."""
+
+    def __init__(self, normalized_shape, weight, bias=None, eps=1e-5):
+        super().__init__(weight, bias)
+        self.normalized_shape, self.eps = tuple(normalized_shape), eps
+
+    def forward(self, input):
+        if self.weight is None:
+            return torch.nn.functional.layer_norm(input, self.normalized_shape, None, None, self.eps)
+        weight, bias = self.cast_bias_weight(input)
+        return torch.nn.functional.layer_norm(input, self.normalized_shape, weight, bias, self.eps)
+
+
+class GGMLGroupNorm(GGMLLayer):
+    """``GGMLOps.GroupNorm`` (ops.py:268-271)."""
+
+    def __init__(self, num_groups, weight, bias=None, eps=1e-5):
+        super().__init__(weight, bias)
+        self.num_groups, self.eps = num_groups, eps
+
+    def forward(self, input):
+        weight, bias = self.cast_bias_weight(input)
+        return torch.nn.functional.group_norm(input, self.num_groups, weight, bias, self.eps)

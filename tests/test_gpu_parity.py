@@ -457,6 +457,35 @@ def test_torch_compile_traces_through_the_custom_op(pkg):
     torch.library.opcheck(torch.ops.ggq.dequantize.default, (data, int(Q.Q4_K), 0, 1))
 
 
+def test_other_layer_types_call_the_same_path(pkg):
+    """GGMLOps.Embedding / Conv2d / LayerNorm / GroupNorm (ops.py:246-271): cast_bias_weight -> dequantize_tensor -> the
+    functional op, against the same op on the oracle's weights."""
+    Q, ops, F = pkg.qtypes.Q, pkg.ops, torch.nn.functional
+    # token embedding, Q6_K table 512 x 256 (the T5 / llama loaders keep big tables quantized, loader.py:377-397)
+    tb = pkg.synth.make_blocks(Q.Q6_K, 512, seed=81)
+    table = torch.from_numpy(oracle.dequant_f16(Q.Q6_K, tb).reshape(512, 256).copy()).to(DEV)
+    emb = ops.GGMLEmbedding(_carrier(pkg, tb, Q.Q6_K, (512, 256)))
+    idx = torch.randint(0, 512, (3, 17), device=DEV)
+    got = emb(idx, out_dtype=torch.float16)
+    assert got.dtype == torch.float16 and torch.equal(got, F.embedding(idx, table))
+    assert torch.equal(emb(idx, out_dtype=torch.float32), F.embedding(idx, table.float()))
+    # conv with a 4-D logical shape stored as Q8_0 blocks, quantized bias
+    wb = pkg.synth.make_blocks(Q.Q8_0, 9, seed=82)                           # 8*4*3*3 = 288 elements = 9 blocks
+    w = torch.from_numpy(oracle.dequant_f16(Q.Q8_0, wb).reshape(8, 4, 3, 3).copy()).to(DEV)
+    conv = ops.GGMLConv2d(_carrier(pkg, wb, Q.Q8_0, (8, 4, 3, 3)), None, padding=1)
+    x = torch.randn(2, 4, 9, 9, device=DEV, dtype=torch.float16)
+    assert torch.equal(conv(x), F.conv2d(x, w, None, 1, 1))
+    # norms keep their (unquantized) F32 weights: the passthrough branch of dequantize_tensor (dequant.py:19-20)
+    g = ops.GGMLTensor(torch.linspace(0.5, 1.5, 64, device=DEV), tensor_type=Q.F32, tensor_shape=(64,))
+    b = ops.GGMLTensor(torch.linspace(-1, 1, 64, device=DEV), tensor_type=Q.F32, tensor_shape=(64,))
+    xs = torch.randn(5, 64, device=DEV, dtype=torch.bfloat16)
+    ln = ops.GGMLLayerNorm((64,), g, b)
+    assert torch.equal(ln(xs), F.layer_norm(xs, (64,), torch.Tensor(g).to(torch.bfloat16), torch.Tensor(b).to(torch.bfloat16), 1e-5))
+    gn = ops.GGMLGroupNorm(8, g, b)
+    xg = torch.randn(2, 64, 4, 4, device=DEV, dtype=torch.float16)
+    assert torch.equal(gn(xg), F.group_norm(xg, 8, torch.Tensor(g).half(), torch.Tensor(b).half(), 1e-5))
+
+
 def test_unsupported_requests_raise(pkg):
     dq, Q = pkg.dequant, pkg.qtypes.Q
     data = torch.zeros(144 * 4, dtype=torch.uint8, device=DEV)
