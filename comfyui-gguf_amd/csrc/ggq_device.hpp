@@ -431,39 +431,43 @@ template <bool RB> GGQ_DEV f32x4 rnd4(f32x4 v)
 // Returns the results of the LAST op of the sequence, not yet rounded to bf16 when RB: the output
 // stage applies that final rounding together with the `.to(dtype)` conversion (for a bf16 result the
 // two coincide in one v_cvt_pk_bf16_f32).
+// Two elements at a time (f2): the multiplies / adds become v_pk_mul_f32 / v_pk_add_f32 and every bf16 rounding is one
+// v_cvt_pk_bf16_f32 plus a shift and a mask to re-widen the pair.
+template <bool RB> GGQ_DEV f2 rnd_pair(f2 v)
+{
+    if constexpr (RB) {
+        const uint32_t p = pack_bf16(v.x, v.y);
+        return f2{bits_f32(p << 16), bits_f32(p & 0xFFFF0000u)};
+    } else {
+        return v;
+    }
+}
+
 template <int KIND, int BIAS, bool RB>
 GGQ_DEV f32x4 quad_f32(const Fields& f, uint32_t t)
 {
-    float q[4], r[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = (float)((t >> (8 * i)) & 0xFFu) - (float)BIAS;   // v_cvt_f32_ubyteN, exact
+    const f2 bias = f2{(float)BIAS, (float)BIAS};
+    const f2 q01 = f2{(float)(t & 0xFFu), (float)((t >> 8) & 0xFFu)} - bias;          // v_cvt_f32_ubyteN, exact
+    const f2 q23 = f2{(float)((t >> 16) & 0xFFu), (float)(t >> 24)} - bias;
     const float d = rnd<RB>((float)h_of(f.dm));
+    f2 r01, r23;
     if constexpr (KIND == K_D) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = d * q[i];
+        const f2 dd{d, d};
+        r01 = dd * q01; r23 = dd * q23;
     } else if constexpr (KIND == K_DM) {
         const float m = rnd<RB>((float)h_of(f.dm >> 16));
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = d * q[i];
-        rnd2<RB>(r[0], r[1]);
-        rnd2<RB>(r[2], r[3]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = r[i] + m;
+        const f2 dd{d, d}, mm{m, m};
+        r01 = rnd_pair<RB>(dd * q01) + mm; r23 = rnd_pair<RB>(dd * q23) + mm;
     } else if constexpr (KIND == K_SCMN) {
-        float dl = d * (float)f.sc, ml = rnd<RB>((float)h_of(f.dm >> 16)) * (float)f.mn;
-        rnd2<RB>(dl, ml);
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = dl * q[i];
-        rnd2<RB>(r[0], r[1]);
-        rnd2<RB>(r[2], r[3]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = r[i] - ml;
+        const f2 dlml = rnd_pair<RB>(f2{d, rnd<RB>((float)h_of(f.dm >> 16))} * f2{(float)f.sc, (float)f.mn});   // (d*sc, dmin*mn)
+        const f2 dl{dlml.x, dlml.x}, ml{dlml.y, dlml.y};
+        r01 = rnd_pair<RB>(dl * q01) - ml; r23 = rnd_pair<RB>(dl * q23) - ml;
     } else {
-        const float dl = rnd<RB>(d * (float)f.sc);
-#pragma unroll
-        for (int i = 0; i < 4; i++) r[i] = dl * q[i];
+        const float dl1 = rnd<RB>(d * (float)f.sc);
+        const f2 dl{dl1, dl1};
+        r01 = dl * q01; r23 = dl * q23;
     }
-    return f32x4{r[0], r[1], r[2], r[3]};
+    return f32x4{r01.x, r01.y, r23.x, r23.y};
 }
 
 // ============================================================================ output stage
