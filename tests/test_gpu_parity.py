@@ -157,6 +157,24 @@ def test_dequant_dtype_modes_full_size(pkg, name, compute):
     assert np.array_equal(_raw(got).view(u), want.view(u))                   # signed nominal scales: no NaN, raw bits
 
 
+def test_randomized_sweep(pkg):
+    """500 seeded random (format, block count, scale mode, dequant_dtype, dtype) cases against the oracle -- block counts
+    drawn around the group boundaries of both team shapes and at random up to 20000."""
+    rng = np.random.default_rng(2024)
+    formats = pkg.qtypes.HIP_QTYPES
+    kinds = ["f16", "bf16", "f32"]
+    for _ in range(500):
+        q = formats[rng.integers(len(formats))]
+        bs, _ = pkg.qtypes.block_geometry(q)
+        n = int(rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4097, int(rng.integers(1, 20000))]))
+        mode = ["nominal", "signed", "adversarial", "raw"][rng.integers(4)]
+        comp, out = kinds[rng.integers(3)], kinds[rng.integers(3)]
+        blocks = pkg.synth.make_blocks(q, n, seed=int(rng.integers(1 << 30)), mode=mode)
+        got = pkg.dequant.dequantize_tensor(_carrier(pkg, blocks, q), _TORCH[out], dequant_dtype=None if comp == "f16" else _TORCH[comp])
+        want = oracle.dequant_tensor(q, blocks, comp, out)
+        assert np.array_equal(_canon(_raw(got), out), _canon(want, out)), (q.name, n, mode, comp, out)
+
+
 def test_trailing_bytes_and_empty(pkg):
     """n_blocks = numel // type_size (dequant.py:41); an empty tensor is legal."""
     q = pkg.qtypes.Q.Q5_K
