@@ -60,6 +60,8 @@ def max_over_ranks(value, device):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if dist.get_backend() == "gloo":                  # test rig only (GGQ_BENCH_BACKEND=gloo): host tensors
+        device = torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -325,7 +327,13 @@ def main():
         sys.exit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local_rank)
+    # GGQ_BENCH_BACKEND=gloo (test rig): exercise the N > 1 code path on a box with fewer GPUs than ranks -- ranks share
+    # devices round-robin and fence through gloo.  The driver's runs use the default: RCCL, one rank per GPU.
+    backend = os.environ.get("GGQ_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_dev:
+        sys.exit(f"LOCAL_RANK={local_rank} but only {n_dev} GPU(s) visible: one rank per GPU")
+    device = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(device)
 
     import torch.distributed as dist
@@ -334,7 +342,10 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL: fence + MAX only
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL: fence + MAX only
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def fence():
         torch.cuda.synchronize(device)
