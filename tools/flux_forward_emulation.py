@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""The hot path in its calling context: every quantized linear of FLUX.1-dev (304 layers, Q4_K_M mix, synthetic weights)
+run the way GGMLOps.Linear.forward does (reference ops.py:242-244) -- dequantize the weight, F.linear, drop it -- for one
+denoising step's worth of tokens, against the same F.linear calls on weights dequantized once up front.
+
+    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5]
+
+Prints one JSON line: ms per emulated step with on-the-fly dequant, with resident dense weights, and the difference
+(the cost of the dequant path per step).  Layers run back to back on one stream; img/txt token counts are not modelled
+separately (every layer sees --tokens rows), modulation layers see 1 row (they act on the conditioning vector)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ggq_pkg import load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", type=int, default=4608)        # 4096 image + 512 text tokens at 1024x1024
+    ap.add_argument("--dtype", default="bfloat16")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mix", default="Q4_K_M")
+    args = ap.parse_args()
+    pkg = load_package()
+    dev = torch.device("cuda:0")
+    dtype = getattr(torch, args.dtype)
+    manifest = pkg.manifests.flux_dev(args.mix)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    layers, inputs = [], {}
+    for name, q, (rows, cols) in manifest:
+        bs, ts = pkg.qtypes.block_geometry(q)
+        n_blocks = rows * cols // bs
+        data = torch.randint(0, 256, (n_blocks, ts), dtype=torch.uint8, device=dev, generator=g)
+        for off in pkg.qtypes.SCALE_FIELDS[q]:                     # small scales: keep activations finite
+            vals = (torch.rand(n_blocks, device=dev, generator=g) * 1e-3 + 1e-4).to(torch.float16)
+            data[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
+        w = pkg.ops.GGMLTensor(data.reshape(-1), tensor_type=q, tensor_shape=(rows, cols))
+        m = 1 if ("mod" in name) else args.tokens
+        if (m, cols) not in inputs:
+            inputs[(m, cols)] = torch.randn(m, cols, device=dev, dtype=dtype) * 0.05
+        layers.append((pkg.ops.GGMLLinear(w), inputs[(m, cols)]))
+
+    def step_quantized():
+        for lin, x in layers:
+            lin(x)
+
+    dense = [pkg.dequant.dequantize_tensor(lin.weight, dtype) for lin, _ in layers]
+
+    def step_dense():
+        for (lin, x), w in zip(layers, dense):
+            torch.nn.functional.linear(x, w)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2], ts[0]
+
+    q_med, q_min = timed(step_quantized)
+    d_med, d_min = timed(step_dense)
+    flops = sum(2.0 * x.shape[0] * lin.weight.shape[0] * lin.weight.shape[1] for lin, x in layers)
+    n_el = sum(lin.weight.shape[0] * lin.weight.shape[1] for lin, _ in layers)
+    print(json.dumps({
+        "workload": f"FLUX.1-dev linears ({len(layers)} layers, {args.mix}, {n_el / 1e9:.2f} G weights), {args.tokens} tokens, {args.dtype}",
+        "ms_per_step_dequant_on_the_fly": round(q_med, 2), "ms_per_step_dense_resident": round(d_med, 2),
+        "dequant_cost_ms_per_step": round(q_med - d_med, 2), "dequant_share_of_step_pct": round(100 * (q_med - d_med) / q_med, 1),
+        "best_ms": {"on_the_fly": round(q_min, 2), "dense": round(d_min, 2)},
+        "gemm_TFLOPs_dense": round(flops / d_med / 1e9, 1),
+        "dense_weight_GB": round(n_el * 2 / 1e9, 1), "packed_weight_GB": round(sum(lin.weight.numel() for lin, _ in layers) / 1e9, 2)}))
+
+
+if __name__ == "__main__":
+    main()
