@@ -10,7 +10,12 @@ reference's own original functions: CPU tensors at load time (loader.py:124,253,
 without a kernel.  Nothing above ``dequantize_tensor`` changes:
 ``GGMLTensor``, ``GGMLOps``, the loader and the nodes keep running the reference's code, so the
 "Unet Loader (GGUF)" node works unchanged.  ``uninstall()`` restores the originals.
+
+``dense_cache_gb`` (or the environment variable ``GGQ_DENSE_CACHE_GB``) additionally keeps dequantized weights resident
+in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM for the per-step dequant work).
 """
+import os
+
 import torch
 
 from . import dequant as _hip
@@ -18,7 +23,7 @@ from . import dequant as _hip
 _installed = {}
 
 
-def install(ref_dequant, ref_ops=None, ref_loader=None):
+def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -27,6 +32,13 @@ def install(ref_dequant, ref_ops=None, ref_loader=None):
     orig = {"dequantize": ref_dequant.dequantize, "dequantize_tensor": ref_dequant.dequantize_tensor}
     unsupported = _hip.GGQUnsupported
     hip_dequantize, hip_dequantize_tensor = _hip.dequantize, _hip.dequantize_tensor
+    if dense_cache_gb is None and os.environ.get("GGQ_DENSE_CACHE_GB"):
+        dense_cache_gb = float(os.environ["GGQ_DENSE_CACHE_GB"])
+    cache = None
+    if dense_cache_gb:
+        from .resident import DenseCache
+        cache = DenseCache(dense_cache_gb * 1e9, hip_dequantize_tensor)
+        hip_dequantize_tensor = cache               # GGQUnsupported from the wrapped function passes straight through
     orig_dequantize, orig_dequantize_tensor = orig["dequantize"], orig["dequantize_tensor"]
 
     # Try the HIP path first; a request it does not serve (CPU-resident bytes at load time, a qtype
@@ -54,8 +66,14 @@ def install(ref_dequant, ref_ops=None, ref_loader=None):
         if mod is not None and getattr(mod, "dequantize_tensor", None) is orig["dequantize_tensor"]:
             mod.dequantize_tensor = dequantize_tensor
             patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
-    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched}
+    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache}
     return orig
+
+
+def dense_cache(ref_dequant):
+    """The DenseCache of an installation (None when the option is off): ``.stats()``, ``.clear()``."""
+    rec = _installed.get(id(ref_dequant))
+    return rec["cache"] if rec else None
 
 
 def uninstall(ref_dequant):
@@ -63,3 +81,5 @@ def uninstall(ref_dequant):
     if rec:
         for mod, name, fn in rec["patched"]:
             setattr(mod, name, fn)
+        if rec.get("cache") is not None:
+            rec["cache"].clear()

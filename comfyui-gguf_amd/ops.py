@@ -62,6 +62,7 @@ class GGMLLayer(torch.nn.Module):
     state-dict hooks and VRAM accounting are the reference's control plane and are not restated."""
 
     dequant_dtype = None                           # ops.py:98; set by the loader nodes (nodes.py:152-157)
+    _dequantize = staticmethod(dequantize_tensor)  # what get_weight calls; resident.DenseCache may be put here
 
     def __init__(self, weight, bias=None):
         super().__init__()
@@ -74,7 +75,7 @@ class GGMLLayer(torch.nn.Module):
     def get_weight(self, tensor, dtype):           # ops.py:166-181 without the LoRA branch
         if tensor is None:
             return None
-        weight = dequantize_tensor(tensor, dtype, self.dequant_dtype)
+        weight = self._dequantize(tensor, dtype, self.dequant_dtype)
         if isinstance(weight, GGMLTensor):         # ops.py:180-181: never hand the subclass on
             weight = weight.as_subclass(torch.Tensor)
         return weight

@@ -504,6 +504,29 @@ def test_other_layer_types_call_the_same_path(pkg):
     assert torch.equal(gn(xg), F.group_norm(xg, 8, torch.Tensor(g).half(), torch.Tensor(b).half(), 1e-5))
 
 
+def test_resident_dense_cache_on_the_real_path(pkg):
+    """resident.DenseCache around the real dequantize_tensor: the resident tensor IS the kernel's output (bit-exact), is
+    reused across forwards of GGMLLinear, and a patched (LoRA) tensor never gets a shared one."""
+    Q = pkg.qtypes.Q
+    blocks = pkg.synth.make_blocks(Q.Q4_K, 64 * 2, seed=91)
+    w = _carrier(pkg, blocks, Q.Q4_K, (64, 512))
+    cache = pkg.resident.DenseCache(1e9, pkg.dequant.dequantize_tensor)
+    d1 = cache(w, torch.bfloat16)
+    assert cache(w, torch.bfloat16) is d1 and cache.stats()["hits"] == 1
+    assert np.array_equal(_bits16(d1), oracle.dequant_tensor(Q.Q4_K, blocks, "f16", "bf16"))
+    assert np.array_equal(_bits16(cache(w, torch.float16)), oracle.dequant_f16(Q.Q4_K, blocks).view(np.uint16))
+    lin = pkg.ops.GGMLLinear(w)
+    lin._dequantize = cache                                                   # instance-level: this layer only
+    x = torch.randn(4, 512, device=DEV, dtype=torch.bfloat16)
+    y = lin(x)
+    assert torch.equal(y, torch.nn.functional.linear(x, d1)) and torch.equal(lin(x), y)
+    assert cache.stats()["misses"] == 2                                       # bf16 and fp16 results, each computed once
+    patched = pkg.ops.GGMLTensor(torch.from_numpy(blocks.reshape(-1).copy()).to(DEV), tensor_type=Q.Q4_K, tensor_shape=(64, 512), patches=[("p", "k")])
+    assert cache(patched, torch.bfloat16) is not cache(patched, torch.bfloat16)
+    with pytest.raises(pkg.dequant.GGQUnsupported):                           # unsupported requests pass straight through
+        cache(pkg.ops.GGMLTensor(torch.zeros(66, dtype=torch.uint8, device=DEV), tensor_type=Q.IQ2_XXS, tensor_shape=(256,)), torch.float16)
+
+
 def test_unsupported_requests_raise(pkg):
     dq, Q = pkg.dequant, pkg.qtypes.Q
     data = torch.zeros(144 * 4, dtype=torch.uint8, device=DEV)

@@ -180,6 +180,47 @@ def test_ggml_tensor_carries_attrs(pkg):
     assert t.copy_(torch.zeros(5, dtype=torch.uint8)) is None          # shape mismatch: logged and ignored (ops.py:70-75)
 
 
+def test_dense_cache_bookkeeping(pkg):
+    """resident.DenseCache on CPU with a counting stand-in for the kernel call: hits, per-mode keys, invalidation by
+    in-place writes and by the packed tensor's death, LRU eviction under the byte budget, the LoRA bypass."""
+    import gc
+    T, Q = pkg.ops.GGMLTensor, pkg.qtypes.Q
+    calls = []
+
+    def fake(tensor, dtype=None, dequant_dtype=None):
+        calls.append((id(tensor), dtype, dequant_dtype))
+        return torch.zeros(getattr(tensor, "tensor_shape", tensor.shape), dtype=dtype or torch.float16)
+
+    cache = pkg.resident.DenseCache(3 * 256 * 2 * 2, fake, require_gpu=False)          # room for three (2, 256) fp16 results
+    mk = lambda: T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256))
+    a, b = mk(), mk()
+    da = cache(a, torch.float16)
+    assert cache(a, torch.float16) is da and len(calls) == 1 and cache.stats()["hits"] == 1
+    assert cache(a, torch.bfloat16) is not da and len(calls) == 2                      # another output dtype: another entry
+    assert cache(a, torch.float16, torch.float32) is not da and len(calls) == 3        # another arithmetic mode too
+    assert cache.stats()["entries"] == 3 and cache.bytes == 3 * 1024
+    db = cache(b, torch.float16)                                                       # over budget: the least recently used goes
+    assert cache.stats()["entries"] == 3 and cache(b, torch.float16) is db
+    assert cache(a, torch.float16) is not da and len(calls) == 5                       # ... which was a's fp16 entry
+    a.add_(1)                                                                          # in-place write into the packed bytes
+    n = len(calls)
+    cache(a, torch.float16)
+    assert len(calls) == n + 1                                                         # version changed: recomputed
+    before = cache.stats()["entries"]
+    del b, db
+    gc.collect()
+    assert cache.stats()["entries"] == before - 1                                      # the entry died with its tensor
+    p = T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256), patches=[("lora", "key")])
+    assert cache(p, torch.float16) is not cache(p, torch.float16) and cache.stats()["bypassed"] == 2   # patched: always fresh
+    plain = torch.zeros(4)
+    assert cache(plain, torch.float32) is not None and cache.stats()["bypassed"] == 3                  # not a GGML tensor
+    big = T(torch.zeros(288 * 64, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(128, 256))
+    cache(big, torch.float16)
+    assert cache.bytes <= cache.budget                                                 # larger than the whole budget: not kept
+    cache.clear()
+    assert cache.stats()["entries"] == 0 and cache.bytes == 0
+
+
 def test_partition_covers_and_balances(pkg):
     sh, man = pkg.sharding, pkg.manifests
     for manifest in (man.flux_dev(), man.sd35_t5(), man.flux_linear_pool(12, 3)):

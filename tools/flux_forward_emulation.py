@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mix", default="Q4_K_M")
+    ap.add_argument("--dense-cache-gb", type=float, default=0.0, help="opt-in resident.DenseCache budget (0 = off, the reference's behaviour)")
     args = ap.parse_args()
     pkg = load_package()
     dev = torch.device("cuda:0")
@@ -47,6 +48,11 @@ def main():
         if (m, cols) not in inputs:
             inputs[(m, cols)] = torch.randn(m, cols, device=dev, dtype=dtype) * 0.05
         layers.append((pkg.ops.GGMLLinear(w), inputs[(m, cols)]))
+
+    cache = None
+    if args.dense_cache_gb:
+        cache = pkg.resident.DenseCache(args.dense_cache_gb * 1e9, pkg.dequant.dequantize_tensor)
+        pkg.ops.GGMLLayer._dequantize = staticmethod(cache)
 
     def step_quantized():
         for lin, x in layers:
@@ -80,6 +86,7 @@ def main():
         "dequant_cost_ms_per_step": round(q_med - d_med, 2), "dequant_share_of_step_pct": round(100 * (q_med - d_med) / q_med, 1),
         "best_ms": {"on_the_fly": round(q_min, 2), "dense": round(d_min, 2)},
         "gemm_TFLOPs_dense": round(flops / d_med / 1e9, 1),
+        "dense_cache": cache.stats() if cache is not None else None,
         "dense_weight_GB": round(n_el * 2 / 1e9, 1), "packed_weight_GB": round(sum(lin.weight.numel() for lin, _ in layers) / 1e9, 2)}))
 
 
