@@ -330,3 +330,12 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
     finally:
         pkg.install.uninstall(rd)
     assert rd.dequantize is orig["dequantize"] and ro.dequantize_tensor is orig["dequantize_tensor"]
+    # with the opt-in resident cache in front: CPU tensors bypass it and still reach the reference's own code
+    pkg.install.install(rd, ro, dense_cache_gb=1)
+    try:
+        assert torch.equal(lin(x), before)
+        st = pkg.install.dense_cache(rd).stats()
+        assert st["bypassed"] >= 1 and st["entries"] == 0
+    finally:
+        pkg.install.uninstall(rd)
+    assert pkg.install.dense_cache(rd) is None
