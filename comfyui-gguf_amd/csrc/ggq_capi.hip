@@ -82,19 +82,8 @@ template <class F, int ARITH> struct TuneFor
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 
-// GGQ_XRUN_LOG2 (environment, read once): force the run length for every format and size (0 = identity mapping
-// everywhere, 6 = runs of 64, ...) -- a measurement knob for A/B runs of bench.py, not a user setting.
-int xrun_override()
-{
-    static const int v = [] {
-        const char* e = getenv("GGQ_XRUN_LOG2");
-        if (!e || !*e) return -1;
-        const int x = atoi(e);
-        return (x >= 0 && x <= 16) ? x : -1;
-    }();
-    return v;
-}
-
+// Measurement knobs (environment, read once; not user settings): GGQ_XRUN_LOG2 forces the run length of the XCD mapping
+// for every format and size (0 = identity mapping everywhere), GGQ_LDS_PAD the occupancy-capping LDS pad.
 int env_int(const char* name, int lo, int hi)
 {
     const char* e = getenv(name);
@@ -109,10 +98,9 @@ template <class F> uint32_t lds_pad_for()
     return o >= 0 ? (uint32_t)o : PadOf<F>::V;
 }
 
-template <class F, int ARITH> uint32_t xrun_for(uint64_t groups)
+template <class T, class F> uint32_t xrun_of(uint64_t groups)      // T = the team shape being launched
 {
-    using T = TuneFor<F, ARITH>;
-    const int o = xrun_override();
+    static const int o = env_int("GGQ_XRUN_LOG2", 0, 16);
     if (o >= 0) return (uint32_t)o;
     return groups * (uint64_t)(T::G * F::BS) >= XRUN_MIN_ELEMENTS ? T::XRUN_LOG2 : 0u;
 }
@@ -137,9 +125,7 @@ hipError_t launch_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    const int o = xrun_override();
-    const uint32_t xrun = o >= 0 ? (uint32_t)o : (groups * (uint64_t)(T::G * F::BS) >= XRUN_MIN_ELEMENTS ? T::XRUN_LOG2 : 0u);
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun);
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
     return hipGetLastError();
 }
 
@@ -162,7 +148,7 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_for<F, ARITH>(groups), T::COOP ? coarse : nullptr, coarse_shift);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_of<T, F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
     return hipGetLastError();
 }
 
