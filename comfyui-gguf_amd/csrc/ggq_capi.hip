@@ -81,6 +81,9 @@ template <class F, int ARITH> struct TuneFor
     : std::conditional<ARITH == AR_F16 || !Tune<F>::COOP || CoopInAllModes<F>::V || Tune<F>::WAVES != 4, Tune<F>, TuneSolo<F>>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
+// ... for the one-wave teams.  The workgroup teams need the run mapping more (identity costs them 8 % on the 3 G-element pool)
+// and still gain 1-2 % from it on single layers (rocprof kernel times, 3072x3072: 7.33 vs 7.45 us, 3072x12288: 17.36 vs 17.66 us).
+constexpr uint64_t XRUN_MIN_ELEMENTS_COOP = 1ull << 23;
 
 // Measurement knobs (environment, read once; not user settings): GGQ_XRUN_LOG2 forces the run length of the XCD mapping
 // for every format and size (0 = identity mapping everywhere), GGQ_LDS_PAD the occupancy-capping LDS pad.
@@ -102,7 +105,7 @@ template <class T, class F> uint32_t xrun_of(uint64_t groups)      // T = the te
 {
     static const int o = env_int("GGQ_XRUN_LOG2", 0, 16);
     if (o >= 0) return (uint32_t)o;
-    return groups * (uint64_t)(T::G * F::BS) >= XRUN_MIN_ELEMENTS ? T::XRUN_LOG2 : 0u;
+    return groups * (uint64_t)(T::G * F::BS) >= (T::COOP ? XRUN_MIN_ELEMENTS_COOP : XRUN_MIN_ELEMENTS) ? T::XRUN_LOG2 : 0u;
 }
 
 thread_local int t_last_hip = 0;
