@@ -396,7 +396,7 @@ def test_reentrant_from_threads_and_never_synchronises(pkg):
     small = pkg.synth.make_blocks(Q.Q4_K, 16, seed=71)
     dsmall = torch.from_numpy(small.reshape(-1).copy()).to(DEV)
     torch.cuda.synchronize()
-    for _ in range(40):                                                      # ~40 x 17 us of queued GPU work
+    for _ in range(300):                                                     # ~300 x 17 us of queued GPU work, enqueued in ~half that
         pkg.dequant.dequantize(dbig, Q.Q4_K, (3072, 12288))
     ev = torch.cuda.Event()
     ev.record()
