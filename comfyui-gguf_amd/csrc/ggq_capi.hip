@@ -23,8 +23,8 @@ using namespace ggq;
 //     6 % faster with fewer rows per wave).  "solo" = one wavefront owns 2048 elements from first load to last store, one
 //     wave per workgroup.  Coop vs solo at bench.py level (headline / per-format table): Q8_0 +6.3 %, Q5_0 +1.2 / +3.7 %,
 //     Q5_K +3.3 / +0.7 %, IQ4_XS +3.2 / +1.3 %, Q4_1 +2.0 %, Q4_0 +0.6 / +3.7 %, IQ4_NL +1.4 / +1.1 %, Q4_K +0.4 / +1.5 %;
-//     Q5_1 does best as 2 waves x 2048 elements (+1.7 %); Q6_K is level with its occupancy-capped solo shape and keeps it;
-//     Q2_K / Q3_K lose 4-7 % with any coop shape and stay solo.  One row per wave (4 waves x 2048) halves the rate -- the
+//     Q2_K +2.7 / 0 %; Q5_1 does best as 2 waves x 2048 elements (+1.7 %); Q6_K is level with its occupancy-capped solo shape
+//     and keeps it; Q3_K loses 1-5 % and stays solo.  One row per wave (4 waves x 2048) halves the rate -- the
 //     per-wave fixed cost dominates -- and a team holds its wave slots idle while it finds its tensor, which is why the
 //     coop teams get the coarse index (run_many below): before it, coop LOST up to 3.5 % on Q5_K / Q5_0 / Q6_K.
 //   * non-temporal stores (+3.4 %; the other cache-policy bits make no difference); non-temporal loads are a wash for
@@ -40,15 +40,19 @@ using namespace ggq;
 // Measurement knobs (environment, read once): GGQ_XRUN_LOG2, GGQ_LDS_PAD force one value for every format.
 template <class F> struct PadOf { static constexpr uint32_t V = 0; };
 template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };
-template <class F> struct TuneSolo {             // one-wave teams x 2048 elements, NT loads, runs of 64 groups
+template <class F> struct PlainLoads { static constexpr bool V = false; };    // non-temporal loads cost these three 2-4 %
+template <> struct PlainLoads<FmtQ2_K> { static constexpr bool V = true; };
+template <> struct PlainLoads<FmtQ3_K> { static constexpr bool V = true; };
+template <> struct PlainLoads<FmtQ6_K> { static constexpr bool V = true; };
+template <class F> struct TuneSolo {             // one-wave teams x 2048 elements, runs of 64 groups
     static constexpr int G = (F::BS == 256) ? 8 : 64;
-    static constexpr bool COOP = false, NTL = true, NTS = true;
+    static constexpr bool COOP = false, NTL = !PlainLoads<F>::V, NTS = true;
     static constexpr int WAVES = 1;
     static constexpr uint32_t XRUN_LOG2 = 6;
 };
-template <class F> struct TuneCoop {             // teams of 4 waves x 4096 elements, NT loads, runs of 32 groups
+template <class F> struct TuneCoop {             // teams of 4 waves x 4096 elements, runs of 32 groups
     static constexpr int G = (F::BS == 256) ? 16 : 128;
-    static constexpr bool COOP = true, NTL = true, NTS = true;
+    static constexpr bool COOP = true, NTL = !PlainLoads<F>::V, NTS = true;
     static constexpr int WAVES = 4;
     static constexpr uint32_t XRUN_LOG2 = 5;
 };
@@ -65,7 +69,6 @@ template <class F> struct Tune : TuneCoop<F> {};
         static constexpr uint32_t XRUN_LOG2 = XRUN_;                                             \
     }
 //       format      G   coop  waves  NT loads  log2(run)
-GGQ_TUNE(FmtQ2_K,    8,  false, 1,    false,    0);
 GGQ_TUNE(FmtQ3_K,    8,  false, 1,    false,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
 GGQ_TUNE(FmtQ5_1,   64,  true,  2,    true,     0);
