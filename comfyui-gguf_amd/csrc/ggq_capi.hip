@@ -23,8 +23,8 @@ using namespace ggq;
 //     6 % faster with fewer rows per wave).  "solo" = one wavefront owns 2048 elements from first load to last store, one
 //     wave per workgroup.  Coop vs solo at bench.py level (headline / per-format table): Q8_0 +6.3 %, Q5_0 +1.2 / +3.7 %,
 //     Q5_K +3.3 / +0.7 %, IQ4_XS +3.2 / +1.3 %, Q4_1 +2.0 %, Q4_0 +0.6 / +3.7 %, IQ4_NL +1.4 / +1.1 %, Q4_K +0.4 / +1.5 %;
-//     Q2_K +2.7 / 0 %; Q5_1 does best as 2 waves x 2048 elements (+1.7 %); Q6_K is level with its occupancy-capped solo shape
-//     and keeps it; Q3_K loses 1-5 % and stays solo.  One row per wave (4 waves x 2048) halves the rate -- the
+//     Q2_K +2.7 / 0 %, Q5_1 +4.5 %; Q6_K is level with its occupancy-capped solo shape and keeps it; Q3_K loses 1-5 %
+//     and stays solo.  One row per wave (4 waves x 2048) halves the rate -- the
 //     per-wave fixed cost dominates -- and a team holds its wave slots idle while it finds its tensor, which is why the
 //     coop teams get the coarse index (run_many below): before it, coop LOST up to 3.5 % on Q5_K / Q5_0 / Q6_K.
 //   * non-temporal stores (+3.4 %; the other cache-policy bits make no difference); non-temporal loads are a wash for
@@ -71,7 +71,6 @@ template <class F> struct Tune : TuneCoop<F> {};
 //       format      G   coop  waves  NT loads  log2(run)
 GGQ_TUNE(FmtQ3_K,    8,  false, 1,    false,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
-GGQ_TUNE(FmtQ5_1,   64,  true,  2,    true,     0);
 #undef GGQ_TUNE
 
 // The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
@@ -81,7 +80,7 @@ template <class F> struct CoopInAllModes { static constexpr bool V = false; };
 template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };     // +7...12 % in every mode
 template <> struct CoopInAllModes<FmtQ4_1> { static constexpr bool V = true; };     // +4 % fp32 arithmetic, level in bf16
 template <class F, int ARITH> struct TuneFor
-    : std::conditional<ARITH == AR_F16 || !Tune<F>::COOP || CoopInAllModes<F>::V || Tune<F>::WAVES != 4, Tune<F>, TuneSolo<F>>::type {};
+    : std::conditional<ARITH == AR_F16 || !Tune<F>::COOP || CoopInAllModes<F>::V, Tune<F>, TuneSolo<F>>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 // ... for the one-wave teams.  The workgroup teams need the run mapping more (identity costs them 8 % on the 3 G-element pool)
