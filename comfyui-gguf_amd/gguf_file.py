@@ -163,6 +163,33 @@ class GGUFFile:
             _native.check(rc, "ggq_gguf_upload")
         return arena
 
+    def upload_tensors(self, device, tensors, threads=0, chunk_bytes=0):
+        """Stream only ``tensors`` (a subset of ``self.tensors``, e.g. one rank's shard of the tensor list) into ONE
+        device buffer: neighbours in the file are coalesced into runs, runs are packed back to back (each run start
+        stays 256-byte aligned), and every run is one streamed upload.  Returns (arena, {tensor name: byte offset})."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ValueError("upload_tensors() targets an AMD GPU (torch device type 'cuda')")
+        order = sorted(tensors, key=lambda t: t.offset)
+        runs, where, pos = [], {}, 0                      # runs: (file offset, nbytes, arena offset)
+        for t in order:
+            if runs and t.offset <= runs[-1][0] + runs[-1][1] + self.alignment:      # adjacent up to the alignment padding
+                f0, n0, a0 = runs[-1]
+                runs[-1] = (f0, max(n0, t.offset + t.nbytes - f0), a0)
+            else:
+                pos = (pos + 255) // 256 * 256
+                runs.append((t.offset, t.nbytes, pos))
+            f0, n0, a0 = runs[-1]
+            where[t.name] = a0 + (t.offset - f0)
+            pos = a0 + n0
+        arena = torch.empty(pos, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            for f0, n0, a0 in runs:
+                rc = _native.lib().ggq_gguf_upload(self._handle(), arena.data_ptr() + a0, f0, n0, int(threads), int(chunk_bytes), stream)
+                _native.check(rc, "ggq_gguf_upload")
+        return arena, where
+
     @staticmethod
     def device_bytes(arena, t):
         return arena[t.offset: t.offset + t.nbytes]

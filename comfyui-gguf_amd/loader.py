@@ -22,6 +22,7 @@ import torch
 from .dequant import dequantize_tensor, is_quantized
 from .gguf_file import ARRAY, INT32, STRING, GGUFFile
 from .ops import GGMLTensor
+from .qtypes import GGML_QUANT_SIZES as _BYTES_KNOWN       # the types sharding.tensor_cost can price
 from .qtypes import GGMLQuantizationType as Q
 
 # architectures the loaders accept (loader.py:12-14)
@@ -130,13 +131,16 @@ def _logical_shape(reader, tensor, arch, compat):
 
 
 def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=False, is_text_model=False, *,
-                   device=None, detect_arch=None, upload_threads=0):
+                   device=None, detect_arch=None, upload_threads=0, shard=None):
     """Read a GGUF file as a state dict of ``GGMLTensor`` (loader.py:51-141).
 
     ``device=None`` (the reference's behaviour): every tensor is a read-only mmap view on the CPU.
     ``device="cuda:N"``: the file's tensor-data section is streamed into ONE HBM buffer and every tensor is a
     view into it -- packed weights resident, 16-byte aligned, ready for the HIP kernels (``GGUFFile.upload``;
     the views keep the arena alive).
+    ``shard=(rank, world_size)`` (with ``device``): one process per GPU, no collectives -- only the tensors
+    ``sharding.partition`` assigns to ``rank`` (every rank computes the same assignment from the file's tensor table alone)
+    are uploaded and returned.
     """
     with GGUFFile(path) as reader:
         selected = _select(reader, handle_prefix)
@@ -144,10 +148,25 @@ def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=Fal
         if compat:
             logging.warning(f"Warning: This gguf model file is loaded in compatibility mode '{compat}' [arch:{arch}]")
 
-        arena = None if device is None else reader.upload(device, threads=upload_threads)
+        where = None
+        if shard is not None:
+            if device is None:
+                raise ValueError("shard=(rank, world_size) selects what is uploaded: it needs device=")
+            from .sharding import partition
+            rank, world = shard
+            manifest = [(key, t.tensor_type, tuple(int(d) for d in reversed(t.shape)) or (1,)) for key, t in selected]
+            costed = [m if m[1] in _BYTES_KNOWN else (m[0], Q.F16, m[2]) for m in manifest]       # unknown types: cost as 2 B/element
+            mine = partition(costed, world)[rank]
+            selected = [selected[i] for i in mine]
+            arena, where = reader.upload_tensors(device, [t for _, t in selected], threads=upload_threads)
+        else:
+            arena = None if device is None else reader.upload(device, threads=upload_threads)
         state_dict, counts = {}, {}
         for key, tensor in selected:
-            raw = tensor.data if arena is None else reader.device_bytes(arena, tensor)
+            if where is not None:
+                raw = arena[where[tensor.name]: where[tensor.name] + tensor.nbytes]
+            else:
+                raw = tensor.data if arena is None else reader.device_bytes(arena, tensor)
             shape = _logical_shape(reader, tensor, arch, compat)
             plain = _PLAIN_DTYPES.get(tensor.tensor_type)
             if plain is not None:

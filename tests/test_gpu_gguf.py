@@ -70,3 +70,27 @@ def test_device_state_dict_dequantizes_to_the_oracle(pkg, tmp_path):
     sd_cpu = pkg.loader.gguf_sd_loader(path)
     for k in keys:
         assert torch.equal(torch.Tensor(sd_cpu[k]), torch.Tensor(sd[k]).cpu())
+
+
+def test_sharded_upload_one_process_per_gpu(pkg, tmp_path):
+    """shard=(rank, world): every rank computes the same tensor-list partition from the file's table alone and uploads
+    only its own tensors (coalesced runs, one arena); the shards are disjoint, cover the file, and hold the file's bytes."""
+    path, spec, packed = _mixed_file(pkg, tmp_path)
+    pre = "model.diffusion_model."
+    world, seen, total_arena = 3, {}, 0
+    for rank in range(world):
+        sd = pkg.loader.gguf_sd_loader(path, device=DEV, shard=(rank, world))
+        assert sd, rank
+        for k, v in sd.items():
+            assert k not in seen
+            seen[k] = rank
+            assert v.is_cuda and v.data_ptr() % 16 == 0
+            name = pre + k
+            if name in packed:
+                assert np.array_equal(torch.Tensor(v).cpu().numpy().reshape(-1), packed[name]), k
+                got = pkg.dequant.dequantize_tensor(v, torch.float16)
+                assert np.array_equal(got.view(torch.int16).cpu().numpy().reshape(-1).view(np.uint16), oracle.dequant_f16(v.tensor_type, packed[name]).view(np.uint16))
+    assert set(seen) == {n[len(pre):] for n, _, _ in spec} | {"bias"}
+    assert len(set(seen.values())) == world                                   # every rank got work
+    with pytest.raises(ValueError, match="device"):
+        pkg.loader.gguf_sd_loader(path, shard=(0, 2))
