@@ -225,7 +225,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 2; }
+int ggq_abi_version(void) { return 3; }
 
 int ggq_supported(int qtype) { return find_format(qtype) ? 1 : 0; }
 

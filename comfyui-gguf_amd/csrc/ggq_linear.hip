@@ -1,0 +1,64 @@
+// ggq_linear.hip -- C ABI over ggq_linear.hpp: y = x @ dequant(W)^T + bias for m <= 4 rows of x, from the packed blocks.
+#include "ggq_linear.hpp"
+#include "../../include/ggq.h"
+
+namespace {
+
+using namespace ggq;
+
+typedef hipError_t (*lin_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, hipStream_t);
+
+template <class F, int OUT, int M>
+hipError_t launch(const void* packed, const void* x, const void* bias, void* y, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    const uint32_t x_bytes = ((uint32_t)M * cols * XBytes<OUT>::V + 15u) & ~15u;
+    const uint32_t lds = x_bytes + LIN_WAVES * LIN_SLICE;
+    // persistent grid: enough waves to keep every CU's slots full, never more workgroups than rows need
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t need = (rows + LIN_WAVES - 1) / LIN_WAVES;
+    const uint32_t per_cu = lds <= 20 * 1024 ? 8u : (lds <= 40 * 1024 ? 4u : (lds <= 80 * 1024 ? 2u : 1u));
+    const uint32_t grid = need < (uint32_t)cus * per_cu ? need : (uint32_t)cus * per_cu;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small<F, OUT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((linear_small<F, OUT, M>), dim3(grid), dim3(LIN_WAVES * 64), lds, s, static_cast<const uint8_t*>(packed),
+                       static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), rows, cols);
+    return hipGetLastError();
+}
+
+struct LinEntry { int qtype, block_size, type_size; lin_fn fn[3][4]; };   // [dtype][m - 1]
+
+#define GGQ_LIN_ROW(F, OUT) {launch<F, OUT, 1>, launch<F, OUT, 2>, launch<F, OUT, 3>, launch<F, OUT, 4>}
+#define GGQ_LIN(F) LinEntry { F::ID, F::BS, F::TS, {GGQ_LIN_ROW(F, OUT_F16), GGQ_LIN_ROW(F, OUT_BF16), GGQ_LIN_ROW(F, OUT_F32)} }
+
+const LinEntry LINEAR[] = {
+    GGQ_LIN(FmtQ4_0), GGQ_LIN(FmtQ4_1), GGQ_LIN(FmtQ5_0), GGQ_LIN(FmtQ5_1), GGQ_LIN(FmtQ8_0),
+    GGQ_LIN(FmtQ2_K), GGQ_LIN(FmtQ3_K), GGQ_LIN(FmtQ4_K), GGQ_LIN(FmtQ5_K), GGQ_LIN(FmtQ6_K),
+    GGQ_LIN(FmtIQ4_NL), GGQ_LIN(FmtIQ4_XS),
+};
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                                void* y, int dtype, void* hip_stream)
+{
+    const LinEntry* e = nullptr;
+    for (const LinEntry& c : LINEAR)
+        if (c.qtype == qtype) e = &c;
+    if (!e) return GGQ_ERR_QTYPE;
+    if (dtype < 0 || dtype > 2 || m < 1 || m > 4) return GGQ_ERR_ARG;
+    if (rows == 0) return GGQ_OK;
+    if (cols == 0 || cols % (uint32_t)e->block_size != 0) return GGQ_ERR_ARG;
+    const uint64_t row_bytes = (uint64_t)cols / (uint32_t)e->block_size * (uint32_t)e->type_size;
+    const uint64_t x_bytes = (uint64_t)m * cols * (dtype == GGQ_F32 ? 4 : 2);
+    if (row_bytes + 15 > (uint64_t)LIN_SLICE || x_bytes + (uint64_t)LIN_WAVES * LIN_SLICE > 150 * 1024) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
+    if (!packed || !x || !y) return GGQ_ERR_ARG;
+    if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
+    const hipError_t err = e->fn[dtype][m - 1](packed, x, bias, y, rows, cols, static_cast<hipStream_t>(hip_stream));
+    return err == hipSuccess ? GGQ_OK : GGQ_ERR_HIP;
+}

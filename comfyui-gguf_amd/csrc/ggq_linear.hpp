@@ -1,0 +1,154 @@
+// ggq_linear.hpp -- gfx950 device code: y = x @ dequant(W)^T (+ bias) for a FEW rows of x (m <= 4), straight from the
+// packed GGUF blocks, without ever writing the dense weight.
+//
+// Where it sits: GGMLOps.Linear.forward (reference ops.py:242-244) dequantizes the whole
+// weight and then calls F.linear.  When x has one to four rows -- FLUX's modulation layers act on the conditioning vector:
+// 76 linears, 27 % of the model's weights, m = batch -- that is 0.56 B/element read + 2 B written + 2 B read again for
+// a matrix-vector product; fused, only the packed bytes move.  Still HBM-bound, still no MFMA: with m <= 4 there is no
+// tile to feed a matrix core, the work is one pass over the packed bytes and m dot products per row.
+//
+// Numerics.  The WEIGHTS are exactly the reference's: decode + quad_f16 produce the same fp16 values bit for bit as the
+// dequant kernels, then the `.to(dtype)` of dequantize_tensor (fp16 -> bf16 RNE / exact) is applied -- so W is the very
+// tensor F.linear would have been given.  The contraction accumulates in fp32 (v_dot2c_f32_f16 / v_dot2c_f32_bf16 for 16-bit
+// activations, separate fp32 multiplies and adds for fp32 ones), chunk by chunk per lane, and reduces the 64 lanes by a butterfly:
+// like any GEMV, the result differs from rocBLAS's by the order of fp32 additions only.  Parity is therefore stated
+// against an fp32 reference of the same op with a tolerance (tests/test_gpu_linear.py), not bit for bit -- which is why
+// this path is OPT-IN and the drop-in default stays dequantize + F.linear.
+//
+// Shape of the work: one WAVE per output row, rows dealt round-robin to a persistent grid.  x (m x cols, 16- or 32-bit)
+// is staged once per workgroup in LDS; per row the wave copies the row's packed bytes (cols/block_size * type_size, e.g.
+// 1728 B for Q4_K x 3072) into its private LDS slice with 16 B/lane loads -- the NEXT row's bytes are already in flight in
+// registers while the current row is decoded -- lane l takes chunks l, l+64, ... (8 weights each), and lane 0 stores y.
+#pragma once
+
+#include "ggq_device.hpp"
+
+namespace ggq {
+
+template <int OUT> struct XBytes { static constexpr int V = (OUT == OUT_F32) ? 4 : 2; };
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 8 elements of a chunk of w[k] * x[mm][e + k], added to acc.  w = the chunk's weights as the reference's fp16
+// values (4 x h2).  16-bit activations use the packed dot instructions (v_dot2c_f32_f16 / v_dot2c_f32_bf16: two products and
+// the fp32 accumulate per lane-op); for bf16 the weights first take the `.to(bfloat16)` rounding of dequantize_tensor.
+template <int OUT>
+GGQ_DEV float dot8(const uint32_t (&w)[4], const uint8_t* xs, uint32_t cols, int mm, uint32_t e, float acc)
+{
+    if constexpr (OUT == OUT_F32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xs + ((size_t)mm * cols + e) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xs + ((size_t)mm * cols + e) * 4 + 16);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const h2 h = as_h2(w[k]);
+            s += (float)h.x * x[2 * k];
+            s += (float)h.y * x[2 * k + 1];
+        }
+        return acc + s;
+    } else {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xs + ((size_t)mm * cols + e) * 2);
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (OUT == OUT_F16) acc = __builtin_amdgcn_fdot2(as_h2(w[k]), as_h2(x[k]), acc, false);
+            else acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2, w[k]), __builtin_bit_cast(s16x2, x[k]), acc, false);
+        }
+        return acc;
+    }
+}
+
+// the 8 weights of a chunk as what dequantize_tensor(..., dtype) would hold: fp16 pairs (OUT_F16 / OUT_F32: widened exactly
+// later) or bf16 pairs (OUT_BF16: RNE from the fp16 values)
+template <class F, int OUT>
+GGQ_DEV void weights8(const Fields& f, uint32_t (&w)[4])
+{
+    const u32x2 lo = quad_f16<F::KIND, F::BIAS>(f, f.t0), hi = quad_f16<F::KIND, F::BIAS>(f, f.t1);
+    w[0] = lo.x; w[1] = lo.y; w[2] = hi.x; w[3] = hi.y;
+    if constexpr (OUT == OUT_BF16) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = h2_to_bf16x2(w[k]);
+    }
+}
+
+constexpr int LIN_NU_MAX = 6;                    // 16-byte load units per lane per row: rows of up to 6128 packed bytes
+constexpr int LIN_SLICE = LIN_NU_MAX * 64 * 16;  // LDS bytes per wave for one row (+ up to 15 bytes of leading misalignment)
+constexpr int LIN_WAVES = 4;
+
+template <class F, int OUT, int M>
+__global__ __launch_bounds__(LIN_WAVES * 64) void linear_small(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+                                                               const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
+                                                               uint32_t rows, uint32_t cols)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const gcptr packed = (gcptr)packed_;
+    constexpr int XB = XBytes<OUT>::V;
+    uint8_t* xs = lds;                                                    // m x cols values of x
+    const uint32_t x_bytes = (uint32_t)M * cols * XB;
+    uint8_t* slice = lds + ((x_bytes + 15u) & ~15u) + (threadIdx.x >> 6) * LIN_SLICE;
+    for (uint32_t o = threadIdx.x * 16u; o < x_bytes; o += LIN_WAVES * 64 * 16)
+        *reinterpret_cast<u32x4*>(xs + o) = *reinterpret_cast<const u32x4*>(x_ + o);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * LIN_WAVES + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * LIN_WAVES;
+    const uint32_t row_bytes = cols / F::BS * F::TS;
+    const uint32_t chunks = cols / 8;                                     // per row
+    constexpr int CPB = F::BS / 8;
+
+    auto fetch = [&](uint32_t r, u32x4 (&pf)[LIN_NU_MAX]) {
+        const uint64_t off = (uint64_t)r * row_bytes;
+        const uint32_t a = (uint32_t)off & 15u, valid = a + row_bytes;
+        const gcptr base = packed + (off - a);
+#pragma unroll
+        for (int u = 0; u < LIN_NU_MAX; u++) {
+            const uint32_t o = (uint32_t)(lane + 64 * u) * 16u;
+            pf[u] = (o < valid) ? gload16<true>(base + o) : u32x4{0, 0, 0, 0};
+        }
+    };
+
+    u32x4 pf[LIN_NU_MAX];
+    if (wave < rows) fetch(wave, pf);
+    for (uint32_t r = wave; r < rows; r += n_waves) {
+        const uint32_t a = (uint32_t)((uint64_t)r * row_bytes) & 15u;
+#pragma unroll
+        for (int u = 0; u < LIN_NU_MAX; u++)
+            if ((uint32_t)(64 * u) * 16u < a + row_bytes) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+        wave_sync();
+        if (r + n_waves < rows) fetch(r + n_waves, pf);                  // next row's bytes fly while this row is decoded
+        float acc[M];
+#pragma unroll
+        for (int mm = 0; mm < M; mm++) acc[mm] = 0.0f;
+        for (uint32_t j = lane; j < chunks; j += 64) {
+            const Fields f = F::template fields<true>(slice + a + (j / CPB) * F::TS, (int)(j % CPB));
+            uint32_t w[4];
+            weights8<F, OUT>(f, w);
+#pragma unroll
+            for (int mm = 0; mm < M; mm++) acc[mm] = dot8<OUT>(w, xs, cols, mm, j * 8, acc[mm]);
+        }
+        wave_sync();                                                      // the slice is rewritten at the top of the loop
+#pragma unroll
+        for (int mm = 0; mm < M; mm++) {
+            float v = acc[mm];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) {
+                if (bias_ != nullptr) {
+                    float b;
+                    if constexpr (OUT == OUT_F32) b = *reinterpret_cast<const float*>(bias_ + (size_t)r * 4);
+                    else if constexpr (OUT == OUT_F16) b = (float)__builtin_bit_cast(_Float16, *reinterpret_cast<const uint16_t*>(bias_ + (size_t)r * 2));
+                    else b = bits_f32((uint32_t)*reinterpret_cast<const uint16_t*>(bias_ + (size_t)r * 2) << 16);
+                    v += b;
+                }
+                uint8_t* dst = y_ + ((size_t)mm * rows + r) * XB;
+                if constexpr (OUT == OUT_F32) *reinterpret_cast<float*>(dst) = v;
+                else if constexpr (OUT == OUT_F16) *reinterpret_cast<uint16_t*>(dst) = __builtin_bit_cast(uint16_t, (_Float16)v);
+                else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+            }
+        }
+    }
+}
+
+}  // namespace ggq

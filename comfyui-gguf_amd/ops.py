@@ -98,9 +98,19 @@ class GGMLLayer(torch.nn.Module):
 
 
 class GGMLLinear(GGMLLayer):
-    """``GGMLOps.Linear`` (ops.py:227-244)."""
+    """``GGMLOps.Linear`` (ops.py:227-244).  ``fuse_small_m`` (opt-in, fused.py): inputs of at most four rows go through the
+    fused dequantize + linear kernel instead of dequantize-then-F.linear."""
+
+    fuse_small_m = False
 
     def forward(self, input):
+        if self.fuse_small_m and is_quantized(self.weight) and input.numel() <= 4 * input.shape[-1]:
+            from .fused import linear_small
+            from .dequant import GGQUnsupported
+            try:
+                return linear_small(input, self.weight.to(input.device), self.bias, self.dequant_dtype)
+            except GGQUnsupported:
+                pass
         if not self.is_ggml_quantized():
             return torch.nn.functional.linear(input, self.weight.to(input.dtype), None if self.bias is None else self.bias.to(input.dtype))
         weight, bias = self.cast_bias_weight(input)

@@ -116,6 +116,18 @@ uint32_t ggq_plan_kernels(const ggq_plan* plan);
 
 void ggq_plan_destroy(ggq_plan* plan);
 
+/* ---- fused dequantize + linear for a few rows of x (opt-in) ------------------------- */
+
+/* y[m, rows] = x[m, cols] @ W^T (+ bias[rows]), W = dequantize_tensor(packed, dtype) of logical shape (rows, cols), 1 <= m <= 4,
+ * computed straight from the packed blocks: the dense weight is never written.  x, bias, y are of `dtype` (ggq_dtype) and
+ * contiguous; x must be 16-byte aligned.  The weights are the reference's values bit for bit; the contraction accumulates in
+ * fp32, so y equals F.linear(x, dequantize_tensor(...), bias) up to the order of fp32 additions (as any two GEMV kernels differ).
+ * Replaces, for m <= 4: GGMLOps.Linear.forward_ggml_cast_weights (ops.py:242-244) = get_weight + F.linear.
+ * GGQ_ERR_ARG if the shape is outside what the kernel stages in LDS (rows of more than 6128 packed bytes, m*cols too large):
+ * the caller keeps dequantize + F.linear. */
+int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                     void* y, int dtype, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

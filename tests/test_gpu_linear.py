@@ -1,0 +1,89 @@
+"""Fused dequantize + linear for 1..4 input rows (include/ggq.h ggq_linear_small, opt-in) on an MI355X.
+
+This is a floating-point CONTRACTION, so -- unlike the dequant kernels -- parity cannot be bit-exact: any two GEMV kernels
+differ by the order of their fp32 additions.  What is checked:
+  * against an fp64 evaluation of the same op on the ORACLE's weights (the reference's values, cast to the activation dtype as
+    dequantize_tensor does): |y - y_ref| <= cols * 2^-24 * sum|w x|  +  eps(dtype) * |y_ref|  -- a worst-case fp32 accumulation
+    bound plus the one final rounding;
+  * that torch's own dequantize-then-F.linear (the drop-in default) satisfies the same bound, i.e. both are the same op.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ALL = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"]
+DT = {"f16": (torch.float16, 2.0 ** -11), "bf16": (torch.bfloat16, 2.0 ** -8), "f32": (torch.float32, 2.0 ** -24)}
+
+
+def _dense_weight(q, blocks, kind, rows, cols):
+    w = oracle.dequant_tensor(q, blocks, "f16", kind)
+    if kind == "f32":
+        return w.astype(np.float64).reshape(rows, cols)
+    if kind == "f16":
+        return w.view(np.float16).astype(np.float64).reshape(rows, cols)
+    return (w.astype(np.uint32) << 16).view(np.float32).astype(np.float64).reshape(rows, cols)
+
+
+def _check(y, x, w64, bias, eps, cols):
+    x64 = x.detach().to(torch.float64).cpu().numpy()
+    ref = x64 @ w64.T
+    bound = (np.abs(x64) @ np.abs(w64).T) * cols * 2.0 ** -24
+    if bias is not None:
+        b64 = bias.detach().to(torch.float64).cpu().numpy()
+        ref = ref + b64
+        bound = bound + np.abs(b64) * 2.0 ** -23
+    err = np.abs(y.detach().to(torch.float64).cpu().numpy() - ref)
+    tol = bound + eps * np.abs(ref) + 1e-30
+    assert np.all(err <= tol), float((err / tol).max())
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f32"])
+def test_fused_linear_against_fp64_reference(pkg, name, kind):
+    q = pkg.qtypes.Q[name]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    dtype, eps = DT[kind]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    for rows, cols, m, with_bias in ((203, 3072, 1, True), (17, 256, 4, False), (1, 1024, 2, True), (1031, 512, 3, False)):
+        blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
+        bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if with_bias else None
+        y = pkg.fused.linear_small(x, w, bias)
+        assert y.shape == (m, rows) and y.dtype == dtype
+        w64 = _dense_weight(q, blocks, kind, rows, cols)
+        _check(y, x, w64, bias, eps, cols)
+        # the drop-in default (dequantize, then torch's GEMM / GEMV) is the same op within the same bound
+        y2 = torch.nn.functional.linear(x, pkg.dequant.dequantize_tensor(w, dtype), bias)
+        _check(y2, x, w64, bias, eps, cols)
+
+
+def test_fused_linear_in_the_layer_and_its_limits(pkg):
+    Q, ops = pkg.qtypes.Q, pkg.ops
+    blocks = pkg.synth.make_tensor_bytes(Q.Q4_K, (96, 3072), seed=3)
+    w = ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=Q.Q4_K, tensor_shape=(96, 3072))
+    bias_blocks = pkg.synth.make_tensor_bytes(Q.Q8_0, (96,), seed=4)
+    qbias = ops.GGMLTensor(torch.from_numpy(bias_blocks).to(DEV), tensor_type=Q.Q8_0, tensor_shape=(96,))
+    lin = ops.GGMLLinear(w, qbias)
+    x = torch.randn(2, 1, 3072, device=DEV, dtype=torch.bfloat16)               # (batch, 1, hidden): the modulation input
+    ref = lin(x)                                                                # default: dequantize + F.linear
+    lin.fuse_small_m = True
+    y = lin(x)
+    assert y.shape == ref.shape == (2, 1, 96) and y.dtype == torch.bfloat16
+    assert torch.allclose(y.float(), ref.float(), rtol=2 ** -6, atol=1e-3)
+    xs = x.transpose(0, 1)                                                      # non-contiguous view: handled by a copy
+    assert torch.equal(lin(xs).transpose(0, 1), y)
+    many = torch.randn(5, 3072, device=DEV, dtype=torch.bfloat16)               # five rows: the layer falls back by itself
+    assert torch.equal(lin(many), torch.nn.functional.linear(many, pkg.dequant.dequantize_tensor(w, torch.bfloat16), pkg.dequant.dequantize_tensor(qbias, torch.bfloat16)))
+    with pytest.raises(pkg.dequant.GGQUnsupported):
+        pkg.fused.linear_small(many, w)
+    with pytest.raises(pkg.dequant.GGQUnsupported):                             # dequant_dtype modes keep the two-step path
+        pkg.fused.linear_small(x, w, None, torch.float32)
+    wide = ops.GGMLTensor(torch.zeros(2 * 65536 // 32 * 34, dtype=torch.uint8, device=DEV), tensor_type=Q.Q8_0, tensor_shape=(2, 65536))
+    with pytest.raises(pkg.dequant.GGQUnsupported):                             # a row of 69632 packed bytes does not fit the LDS staging
+        pkg.fused.linear_small(torch.zeros(1, 65536, device=DEV, dtype=torch.float16), wide)
