@@ -13,6 +13,11 @@ without a kernel.  Nothing above ``dequantize_tensor`` changes:
 
 ``dense_cache_gb`` (or the environment variable ``GGQ_DENSE_CACHE_GB``) additionally keeps dequantized weights resident
 in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM for the per-step dequant work).
+
+``fused_small_m`` (or ``GGQ_FUSED_SMALL_M=1``; needs ``ref_ops``) wraps ``GGMLOps.Linear.forward_ggml_cast_weights``
+(reference ops.py:242-244): inputs of one to four rows (FLUX's modulation layers) go through the fused dequantize +
+linear kernel (fused.py) when weight and input qualify, everything else -- LoRA-patched weights included -- through the
+reference's method.  Opt-in because the result matches F.linear up to fp32 summation order, not bit for bit.
 """
 import os
 
@@ -23,7 +28,7 @@ from . import dequant as _hip
 _installed = {}
 
 
-def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None):
+def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -66,8 +71,33 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None):
         if mod is not None and getattr(mod, "dequantize_tensor", None) is orig["dequantize_tensor"]:
             mod.dequantize_tensor = dequantize_tensor
             patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
+    if fused_small_m is None:
+        fused_small_m = os.environ.get("GGQ_FUSED_SMALL_M", "0") not in ("", "0")
+    if fused_small_m:
+        if ref_ops is None:
+            raise ValueError("fused_small_m patches GGMLOps.Linear: pass ref_ops")
+        patched.append(_fuse_small_m(ref_ops.GGMLOps.Linear, unsupported))
     _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache}
     return orig
+
+
+def _fuse_small_m(linear_cls, unsupported):
+    """Wrap ``linear_cls.forward_ggml_cast_weights``; returns the (owner, name, original) record uninstall() restores."""
+    from .fused import MAX_ROWS, linear_small
+    reference_forward = linear_cls.forward_ggml_cast_weights
+
+    def forward_ggml_cast_weights(self, input):
+        weight = self.weight
+        if input.numel() <= MAX_ROWS * input.shape[-1] and weight is not None and input.is_cuda:
+            try:
+                return linear_small(input, weight.to(input.device), self.bias, self.dequant_dtype)
+            except unsupported:
+                pass
+        return reference_forward(self, input)
+
+    forward_ggml_cast_weights.__wrapped__ = reference_forward
+    linear_cls.forward_ggml_cast_weights = forward_ggml_cast_weights
+    return (linear_cls, "forward_ggml_cast_weights", reference_forward)
 
 
 def dense_cache(ref_dequant):

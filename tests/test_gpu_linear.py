@@ -87,3 +87,44 @@ def test_fused_linear_in_the_layer_and_its_limits(pkg):
     wide = ops.GGMLTensor(torch.zeros(2 * 65536 // 32 * 34, dtype=torch.uint8, device=DEV), tensor_type=Q.Q8_0, tensor_shape=(2, 65536))
     with pytest.raises(pkg.dequant.GGQUnsupported):                             # a row of 69632 packed bytes does not fit the LDS staging
         pkg.fused.linear_small(torch.zeros(1, 65536, device=DEV, dtype=torch.float16), wide)
+
+
+def test_install_fused_small_m_wraps_the_linear_forward(pkg):
+    """install(..., fused_small_m=True) wraps ``GGMLOps.Linear.forward_ggml_cast_weights`` (reference ops.py:242-244).  The
+    reference is not on the GPU box, so the wrapper is driven on a class with that method's shape: small inputs take the fused
+    kernel, larger ones and LoRA-patched weights the wrapped method, and uninstalling restores it."""
+    Q, ops = pkg.qtypes.Q, pkg.ops
+
+    class Linear(ops.GGMLLinear):
+        calls = 0
+
+        def forward_ggml_cast_weights(self, input):
+            type(self).calls += 1
+            weight, bias = self.cast_bias_weight(input)
+            return torch.nn.functional.linear(input, weight, bias)
+
+        def forward(self, input):
+            return self.forward_ggml_cast_weights(input)
+
+    original = Linear.forward_ggml_cast_weights
+    blocks = pkg.synth.make_tensor_bytes(Q.Q6_K, (64, 1024), seed=8)
+    w = ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=Q.Q6_K, tensor_shape=(64, 1024))
+    lin = Linear(w)
+    x = torch.randn(1, 1024, device=DEV, dtype=torch.float16)
+    ref = lin(x)
+    record = pkg.install._fuse_small_m(Linear, pkg.dequant.GGQUnsupported)
+    try:
+        before = Linear.calls
+        y = lin(x)
+        assert Linear.calls == before                                            # the fused kernel served it
+        assert torch.allclose(y.float(), ref.float(), rtol=2 ** -9, atol=1e-3)
+        big = torch.randn(8, 1024, device=DEV, dtype=torch.float16)
+        assert torch.equal(lin(big), torch.nn.functional.linear(big, pkg.dequant.dequantize_tensor(w, torch.float16)))
+        assert Linear.calls == before + 1
+        w.patches = [("lora", "key")]                                            # patched weight: needs the dense tensor
+        lin(x)
+        assert Linear.calls == before + 2
+    finally:
+        owner, name, fn = record
+        setattr(owner, name, fn)
+    assert Linear.forward_ggml_cast_weights is original

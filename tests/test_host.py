@@ -315,7 +315,7 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
     lin = ro.GGMLOps.Linear(512, 8)
     lin.weight, lin.bias = torch.nn.Parameter(weight, requires_grad=False), None
     x = torch.randn(3, 512)
-    before = lin(x)
+    before, before_row = lin(x), lin(x[:1])
     orig = pkg.install.install(rd, ro)
     try:
         assert rd.dequantize is not orig["dequantize"] and ro.dequantize_tensor is rd.dequantize_tensor
@@ -339,3 +339,16 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
     finally:
         pkg.install.uninstall(rd)
     assert pkg.install.dense_cache(rd) is None
+    # with the opt-in fused small-m linear: a CPU input is not the kernel's business -> the reference's method, same result
+    ref_forward = ro.GGMLOps.Linear.forward_ggml_cast_weights
+    pkg.install.install(rd, ro, fused_small_m=True)
+    try:
+        assert ro.GGMLOps.Linear.forward_ggml_cast_weights is not ref_forward
+        assert torch.equal(lin(x), before)
+        assert torch.equal(lin(x[:1]), before_row)
+    finally:
+        pkg.install.uninstall(rd)
+    assert ro.GGMLOps.Linear.forward_ggml_cast_weights is ref_forward
+    with pytest.raises(ValueError):
+        pkg.install.install(rd, fused_small_m=True)
+    pkg.install.uninstall(rd)

@@ -28,8 +28,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mix", default="Q4_K_M")
     ap.add_argument("--dense-cache-gb", type=float, default=0.0, help="opt-in resident.DenseCache budget (0 = off, the reference's behaviour)")
+    ap.add_argument("--fused-small-m", action="store_true", help="opt-in fused dequantize + linear for the 1-row (modulation) layers")
     args = ap.parse_args()
     pkg = load_package()
+    pkg.ops.GGMLLinear.fuse_small_m = args.fused_small_m
     dev = torch.device("cuda:0")
     dtype = getattr(torch, args.dtype)
     manifest = pkg.manifests.flux_dev(args.mix)
