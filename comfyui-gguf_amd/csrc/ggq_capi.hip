@@ -1,6 +1,7 @@
 // ggq_capi.hip -- the C ABI of include/ggq.h over the kernels of ggq_device.hpp.
 // Host side is plain C++ on the HIP runtime; nothing here knows about torch.
 #include "ggq_device.hpp"
+#include "ggq_host.hpp"
 #include "../../include/ggq.h"
 #include "../../include/ggq_gguf.h"
 
@@ -186,12 +187,6 @@ const FormatEntry* find_format(int qtype)
     return nullptr;
 }
 
-int hip_fail(hipError_t e)
-{
-    t_last_hip = (int)e;
-    return GGQ_ERR_HIP;
-}
-
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int check_tensor(const FormatEntry* f, const void* packed, const void* out, uint64_t n_blocks, int compute_dtype, int out_dtype)
@@ -214,6 +209,12 @@ struct Segment {
 };
 
 }  // namespace
+
+int ggq::hip_fail(hipError_t e)
+{
+    t_last_hip = (int)e;
+    return GGQ_ERR_HIP;
+}
 
 struct ggq_plan {
     std::vector<Segment> segments;
@@ -339,6 +340,8 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
 int ggq_plan_launch(const ggq_plan* plan, void* hip_stream)
 {
     if (!plan) return GGQ_ERR_ARG;
+    int device = plan->device;
+    if (!plan->segments.empty() && (hipGetDevice(&device) != hipSuccess || device != plan->device)) return GGQ_ERR_ARG;   // the table lives on the plan's device
     for (const Segment& seg : plan->segments) {
         const hipError_t e = seg.fmt->many[seg.compute_dtype][seg.out_dtype](plan->dev_table + seg.first, seg.count, seg.groups, plan->dev_coarse + seg.coarse_first,
                                                                                seg.coarse_shift, static_cast<hipStream_t>(hip_stream));

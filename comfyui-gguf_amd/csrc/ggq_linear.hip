@@ -1,6 +1,9 @@
 // ggq_linear.hip -- C ABI over ggq_linear.hpp: y = x @ dequant(W)^T + bias for m <= 4 rows of x, from the packed blocks.
 #include "ggq_linear.hpp"
+#include "ggq_host.hpp"
 #include "../../include/ggq.h"
+
+#include <atomic>
 
 namespace {
 
@@ -8,21 +11,41 @@ using namespace ggq;
 
 typedef hipError_t (*lin_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, hipStream_t);
 
+constexpr int MAX_DEVICES = 64;
+
+// compute units of the current device, asked once per device (the launch path runs per layer per step)
+uint32_t compute_units(int dev)
+{
+    static std::atomic<int> cached[MAX_DEVICES];
+    if (dev < 0 || dev >= MAX_DEVICES) return 256;
+    int cus = cached[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return (uint32_t)cus;
+}
+
 template <class F, int OUT, int M>
 hipError_t launch(const void* packed, const void* x, const void* bias, void* y, uint32_t rows, uint32_t cols, hipStream_t s)
 {
     const uint32_t x_bytes = ((uint32_t)M * cols * XBytes<OUT>::V + 15u) & ~15u;
     const uint32_t lds = x_bytes + LIN_WAVES * LIN_SLICE;
     // persistent grid: enough waves to keep every CU's slots full, never more workgroups than rows need
-    int dev = 0, cus = 256;
+    int dev = 0;
     (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t cus = compute_units(dev);
     const uint32_t need = (rows + LIN_WAVES - 1) / LIN_WAVES;
     const uint32_t per_cu = lds <= 20 * 1024 ? 8u : (lds <= 40 * 1024 ? 4u : (lds <= 80 * 1024 ? 2u : 1u));
-    const uint32_t grid = need < (uint32_t)cus * per_cu ? need : (uint32_t)cus * per_cu;
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small<F, OUT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+    const uint32_t grid = need < cus * per_cu ? need : cus * per_cu;
+    if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
+        static std::atomic<uint64_t> raised{0};
+        const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
+        if (!(raised.load(std::memory_order_relaxed) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small<F, OUT, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     hipLaunchKernelGGL((linear_small<F, OUT, M>), dim3(grid), dim3(LIN_WAVES * 64), lds, s, static_cast<const uint8_t*>(packed),
                        static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), rows, cols);
@@ -60,5 +83,5 @@ extern "C" int ggq_linear_small(int qtype, const void* packed, uint32_t rows, ui
     if (!packed || !x || !y) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
     const hipError_t err = e->fn[dtype][m - 1](packed, x, bias, y, rows, cols, static_cast<hipStream_t>(hip_stream));
-    return err == hipSuccess ? GGQ_OK : GGQ_ERR_HIP;
+    return err == hipSuccess ? GGQ_OK : hip_fail(err);
 }

@@ -107,7 +107,8 @@ typedef struct ggq_plan ggq_plan;
  * while the tensors keep their addresses (packed weights resident in HBM). */
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out);
 
-/* Enqueue the whole plan on `hip_stream`: one kernel per (qtype, compute_dtype, out_dtype) present. */
+/* Enqueue the whole plan on `hip_stream`: one kernel per (qtype, compute_dtype, out_dtype) present.  The calling
+ * thread's current device must be the one the plan was created on (its tables live there): GGQ_ERR_ARG otherwise. */
 int ggq_plan_launch(const ggq_plan* plan, void* hip_stream);
 
 /* Algorithmic bytes one launch moves (packed read + dense write), and its kernel count. */
