@@ -6,6 +6,7 @@
 //      straight from ggq_device.hpp, over a working set >> the 256 MiB Infinity Cache.
 // Build: see tests/microbench/Makefile.   Run: ./ggq_microbench [parity|ceil|variants|formats|all]
 #include "../../comfyui-gguf_amd/csrc/ggq_device.hpp"
+#include "ggq_stream.hpp"
 #include "../../include/ggq.h"
 
 #include <algorithm>
@@ -917,6 +918,93 @@ static void pmc_sequence()
     }
 }
 
+// ---- persistent, software-pipelined engine (ggq_stream.hpp) against the shipped one-shot shapes ----------------------
+static uint8_t* stream_trash()
+{
+    static uint8_t* t = nullptr;
+    if (!t) HIP_CHECK(hipMalloc(&t, 4096));
+    return t;
+}
+
+template <class F, int G, bool NTL, int D>
+static bool check_stream()
+{
+    const QT* q = nullptr;
+    for (const QT& x : QTS) if (x.id == F::ID) q = &x;
+    bool ok = true;
+    // two tensors per launch (ragged first one), grids from "fewer groups than waves" to "many turns of the ring"
+    for (uint64_t n : {(uint64_t)1, (uint64_t)(3 * G + 1), (uint64_t)(G * 40), (uint64_t)(G * 333 + 5)}) {
+        for (uint32_t grid : {8u, 64u}) {
+            for (uint32_t xr : {0u, 2u}) {
+                const uint64_t n2 = (uint64_t)G * 17;
+                std::vector<uint8_t> p1, p2; make_blocks(*q, n, (int)(n & 1), p1); make_blocks(*q, n2, 0, p2);
+                std::vector<uint16_t> want((n + n2) * F::BS), got((n + n2) * F::BS);
+                ggq_oracle_dequant_f16(F::ID, p1.data(), n, want.data());
+                ggq_oracle_dequant_f16(F::ID, p2.data(), n2, want.data() + n * F::BS);
+                const uint64_t p1pad = (p1.size() + 255) / 256 * 256;
+                uint8_t *dp, *dout;
+                HIP_CHECK(hipMalloc(&dp, p1pad + p2.size())); HIP_CHECK(hipMalloc(&dout, (n + n2) * F::BS * 2 + 256));
+                HIP_CHECK(hipMemcpy(dp, p1.data(), p1.size(), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemcpy(dp + p1pad, p2.data(), p2.size(), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemset(dout, 0xCD, (n + n2) * F::BS * 2 + 256));
+                const uint64_t g1 = (n + G - 1) / G, g2 = (n2 + G - 1) / G;
+                const ggq::Desc tab[2] = {{dp, dout, n, 0}, {dp + p1pad, dout + n * F::BS * 2, n2, g1}};
+                ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, sizeof tab)); HIP_CHECK(hipMemcpy(dt, tab, sizeof tab, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL((ggq::dequant_many_stream<F, G, ggq::OUT_F16, NTL, true, D>), dim3(grid), dim3(64), 0, nullptr, dt, 2u, g1 + g2, xr, nullptr, 0u, stream_trash());
+                HIP_CHECK(hipDeviceSynchronize());
+                HIP_CHECK(hipMemcpy(got.data(), dout, (n + n2) * F::BS * 2, hipMemcpyDeviceToHost));
+                uint8_t guard[256]; HIP_CHECK(hipMemcpy(guard, dout + (n + n2) * F::BS * 2, 256, hipMemcpyDeviceToHost));
+                for (uint64_t i = 0; i < (n + n2) * F::BS; i++) ok &= canon16(got[i]) == canon16(want[i]);
+                for (int g = 0; g < 256; g++) ok &= guard[g] == 0xCD;
+                HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(dout)); HIP_CHECK(hipFree(dt));
+            }
+        }
+    }
+    return ok;
+}
+
+template <class F, int G, bool NTL, int D>
+static void ab_add_stream(AB& ab, const char* name, Pool& P, uint32_t waves_per_cu, uint32_t xrun)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    ab.to_free.push_back(dt);
+    const uint32_t grid = 256u * waves_per_cu, n = (uint32_t)d.size();
+    uint8_t* trash = stream_trash();
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s stream G=%d ntl=%d D=%d waves/CU=%u xrun=%u", name, G, (int)NTL, D, waves_per_cu, xrun);
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many_stream<F, G, ggq::OUT_F16, NTL, true, D>), dim3(grid), dim3(64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u, trash); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_stream<F, G, NTL, D>()});
+}
+
+template <class F, int G, bool NTL, bool COOP_BASE>
+static void ab_stream(const char* name, int qi, int pairs)
+{
+    Pool P = make_pool(QTS[qi], pairs);
+    printf("POOL %s pairs=%d\n", name, pairs);
+    AB ab;
+    if (COOP_BASE) ab_add<F, 2 * G, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, 5);      // the shipped team shape
+    else ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P, F::ID == 14 ? 4096 : 0, 6);      // Q6_K ships with the 4 KiB occupancy pad
+    const char* only = getenv("GGQ_STREAM_ONLY");                                                   // e.g. "D4" to cut the sweep
+    if (!only || strstr(only, "D2")) { ab_add_stream<F, G, NTL, 2>(ab, name, P, 8, 6); ab_add_stream<F, G, NTL, 2>(ab, name, P, 16, 6); ab_add_stream<F, G, NTL, 2>(ab, name, P, 24, 6); }
+    if (!only || strstr(only, "D4")) { ab_add_stream<F, G, NTL, 4>(ab, name, P, 4, 6); ab_add_stream<F, G, NTL, 4>(ab, name, P, 8, 6); ab_add_stream<F, G, NTL, 4>(ab, name, P, 12, 6); ab_add_stream<F, G, NTL, 4>(ab, name, P, 16, 6); }
+    if (!only || strstr(only, "D6")) { ab_add_stream<F, G, NTL, 6>(ab, name, P, 4, 6); ab_add_stream<F, G, NTL, 6>(ab, name, P, 8, 6); }
+    ab.run(9, 3);
+    free_pool(P);
+}
+
+static void ab_stream_all()
+{
+    ab_stream<ggq::FmtQ4_K, 8, true, true>("Q4_K", 7, 64);
+    ab_stream<ggq::FmtQ2_K, 8, false, true>("Q2_K", 5, 64);
+    ab_stream<ggq::FmtQ4_0, 64, true, true>("Q4_0", 0, 64);
+    ab_stream<ggq::FmtQ8_0, 64, true, true>("Q8_0", 4, 64);
+    ab_stream<ggq::FmtQ6_K, 8, false, false>("Q6_K", 9, 64);
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -940,5 +1028,6 @@ int main(int argc, char** argv)
     if (what == "abocc") ab_occ1_all();
     if (what == "fillrows") fill_rows();
     if (what == "fillpol") fill_policy();
+    if (what == "abstream") ab_stream_all();
     return rc ? 1 : 0;
 }
