@@ -57,7 +57,7 @@ template <class F> struct TuneCoop {             // teams of 4 waves x 4096 elem
     static constexpr int WAVES = 4;
     static constexpr uint32_t XRUN_LOG2 = 5;
 };
-// Tune<F> = the shape for the stock fp16 arithmetic (every output dtype); TuneFor<F, ARITH> below picks per mode.
+// Tune<F> = the shape for the stock fp16 arithmetic and fp16 output; TuneFor<F, ARITH, OUT> below picks per mode.
 #ifdef GGQ_SOLO_ONLY      /* A/B builds only: one-wave teams for every format */
 template <class F> struct Tune : TuneSolo<F> {};
 #else
@@ -80,8 +80,23 @@ GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
 template <class F> struct CoopInAllModes { static constexpr bool V = false; };
 template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };     // +7...12 % in every mode
 template <> struct CoopInAllModes<FmtQ4_1> { static constexpr bool V = true; };     // +4 % fp32 arithmetic, level in bf16
-template <class F, int ARITH> struct TuneFor
-    : std::conditional<ARITH == AR_F16 || !Tune<F>::COOP || CoopInAllModes<F>::V, Tune<F>, TuneSolo<F>>::type {};
+// ... and so does the bf16 output cast (1.5 more conversions per element, the production case: FLUX computes in bf16) for the
+// formats with the heavier decode.  Same-box alternation of two builds over all formats and output dtypes
+// (tools/mode_table.py, profiles/r01_mode_table_coop_vs_solo_cast_outputs.json), solo vs coop with bf16 output: Q5_K +5.5 %,
+// Q4_K +4.0 %, Q2_K +4.0 %, IQ4_NL +3.8 %, IQ4_XS +3.0 %; level for Q4_0 / Q5_0; Q4_1 -2.6 %, Q5_1 -2.1 %, Q8_0 -4.2 % (stay coop).
+// fp32 output keeps the coop shape everywhere (solo: -1...-9 %, level for Q5_0 / Q5_K / IQ4_XS).
+#ifdef GGQ_SOLO_CAST_OUT      /* A/B builds only: one-wave teams whenever the output is not fp16 */
+template <class F, int OUT> struct CoopForOut { static constexpr bool V = OUT == OUT_F16; };
+#else
+template <class F, int OUT> struct CoopForOut { static constexpr bool V = true; };
+template <> struct CoopForOut<FmtQ2_K, OUT_BF16> { static constexpr bool V = false; };
+template <> struct CoopForOut<FmtQ4_K, OUT_BF16> { static constexpr bool V = false; };
+template <> struct CoopForOut<FmtQ5_K, OUT_BF16> { static constexpr bool V = false; };
+template <> struct CoopForOut<FmtIQ4_NL, OUT_BF16> { static constexpr bool V = false; };
+template <> struct CoopForOut<FmtIQ4_XS, OUT_BF16> { static constexpr bool V = false; };
+#endif
+template <class F, int ARITH, int OUT> struct TuneFor
+    : std::conditional<!Tune<F>::COOP || ((ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V), Tune<F>, TuneSolo<F>>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 // ... for the one-wave teams.  The workgroup teams need the run mapping more (identity costs them 8 % on the 3 G-element pool)
@@ -138,10 +153,18 @@ hipError_t launch_one(const Desc& d, hipStream_t s)
 template <class F, int ARITH, int OUT>
 hipError_t run_one(const Desc& d, hipStream_t s)
 {
-    if constexpr (SoloWhenSmall<F>::V && TuneFor<F, ARITH>::COOP) {
-        if (d.n_blocks * (uint64_t)F::BS < XRUN_MIN_ELEMENTS) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
+    using Big = TuneFor<F, ARITH, OUT>;                              // the shape of whole-model launches
+    using Fp16Out = TuneFor<F, ARITH, OUT_F16>;
+    const bool layer_sized = d.n_blocks * (uint64_t)F::BS < XRUN_MIN_ELEMENTS;
+    if constexpr (SoloWhenSmall<F>::V && Big::COOP) {
+        if (layer_sized) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
     }
-    return launch_one<TuneFor<F, ARITH>, F, ARITH, OUT>(d, s);
+    // one-wave teams chosen for the output cast only (CoopForOut): that is a whole-model effect too -- at layer size the
+    // emulated FLUX step (bf16 output, one launch per layer) is level to 0.2 ms slower with them, so single layers stay coop
+    if constexpr (!Big::COOP && Fp16Out::COOP) {
+        if (layer_sized) return launch_one<Fp16Out, F, ARITH, OUT>(d, s);
+    }
+    return launch_one<Big, F, ARITH, OUT>(d, s);
 }
 
 // The coarse index replaces the binary search only for the COOP teams: bench.py, alternating builds on one box, measured
@@ -150,7 +173,7 @@ hipError_t run_one(const Desc& d, hipStream_t s)
 template <class F, int ARITH, int OUT>
 hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32_t* coarse, uint32_t coarse_shift, hipStream_t s)
 {
-    using T = TuneFor<F, ARITH>;
+    using T = TuneFor<F, ARITH, OUT>;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
@@ -160,15 +183,16 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
 
 struct FormatEntry {
     int qtype, block_size, type_size;
-    int group[3];          // blocks per group, by compute dtype (the team shape may differ per arithmetic mode)
+    int group[3][3];       // blocks per group, [compute dtype][out dtype] (the team shape may differ per mode)
     one_fn one[3][3];      // [compute dtype][out dtype]
     many_fn many[3][3];
 };
 
 #define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
+#define GGQ_GROUPS(F, AR) {TuneFor<F, AR, OUT_F16>::G, TuneFor<F, AR, OUT_BF16>::G, TuneFor<F, AR, OUT_F32>::G}
 #define GGQ_FORMAT(F)                                                                          \
     FormatEntry {                                                                              \
-        F::ID, F::BS, F::TS, {TuneFor<F, AR_F16>::G, TuneFor<F, AR_BF16>::G, TuneFor<F, AR_F32>::G},     \
+        F::ID, F::BS, F::TS, {GGQ_GROUPS(F, AR_F16), GGQ_GROUPS(F, AR_BF16), GGQ_GROUPS(F, AR_F32)},     \
         {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
         {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)}    \
     }
@@ -296,7 +320,7 @@ int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)
                     const ggq_desc& d = descs[i];
                     if (d.qtype != FORMATS[fi].qtype || d.compute_dtype != cd || d.out_dtype != od || d.n_blocks == 0) continue;
                     table.push_back(Desc{static_cast<const uint8_t*>(d.packed), static_cast<uint8_t*>(d.out), d.n_blocks, seg.groups});
-                    seg.groups += (d.n_blocks + FORMATS[fi].group[cd] - 1) / FORMATS[fi].group[cd];
+                    seg.groups += (d.n_blocks + FORMATS[fi].group[cd][od] - 1) / FORMATS[fi].group[cd][od];
                     seg.count++;
                     plan->bytes += d.n_blocks * ((uint64_t)FORMATS[fi].type_size + (uint64_t)FORMATS[fi].block_size * (od == GGQ_F32 ? 4 : 2));
                 }
