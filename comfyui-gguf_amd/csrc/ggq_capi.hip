@@ -159,11 +159,14 @@ hipError_t run_one(const Desc& d, hipStream_t s)
     if constexpr (SoloWhenSmall<F>::V && Big::COOP) {
         if (layer_sized) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
     }
-    // one-wave teams chosen for the output cast only (CoopForOut): that is a whole-model effect too -- at layer size the
-    // emulated FLUX step (bf16 output, one launch per layer) is level to 0.2 ms slower with them, so single layers stay coop
+    // one-wave teams chosen for the output cast only (CoopForOut): a whole-model effect too.  At layer size, bf16 output, rocprof
+    // kernel times coop vs solo: 3072x3072 Q4_K 6.09 vs 6.52 us, Q5_K 6.21 vs 6.76, IQ4_XS 6.19 vs 6.80; 3072x12288 Q5_K 18.1 vs 18.9,
+    // IQ4_XS 17.1 vs 17.9, Q4_K level (profiles/r01_layer_kernel_times_bf16_out_coop_vs_solo.json): single layers stay coop
+#ifndef GGQ_CAST_SOLO_AT_LAYER_SIZE      /* A/B builds define it */
     if constexpr (!Big::COOP && Fp16Out::COOP) {
         if (layer_sized) return launch_one<Fp16Out, F, ARITH, OUT>(d, s);
     }
+#endif
     return launch_one<Big, F, ARITH, OUT>(d, s);
 }
 
