@@ -131,6 +131,7 @@ constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
+typedef hipError_t (*rows_fn)(const void*, const int64_t*, void*, uint64_t, uint32_t, uint64_t, hipStream_t);
 
 // Single tensors of layer size (per-layer calls, ops.py:177; rocprof kernel times of 3072x3072 / 3072x12288 tensors, solo vs coop
 // builds): the coop shape is 3-8 % FASTER for the 4/5-bit formats (Q4_K 6.10 vs 6.61 us, 17.7 vs 18.1 us) but 3-8 % SLOWER for
@@ -184,11 +185,30 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     return hipGetLastError();
 }
 
+// the embedding lookup: a few hundred rows of one table per call -- one-wave teams, plain loads (a token may repeat)
+template <class F, int ARITH, int OUT>
+hipError_t run_rows(const void* packed, const int64_t* indices, void* out, uint64_t n_rows, uint32_t row_blocks, uint64_t n_indices, hipStream_t s)
+{
+    using T = TuneSolo<F>;
+    constexpr uint64_t MAX_GRID_Y = 65535, OUT_BYTES = (OUT == OUT_F32) ? 4 : 2;
+    const uint32_t groups_per_row = (row_blocks + T::G - 1) / T::G;
+    for (uint64_t first = 0; first < n_indices; first += MAX_GRID_Y) {          // grid.y = output rows
+        const uint64_t rows = std::min(MAX_GRID_Y, n_indices - first);
+        hipLaunchKernelGGL((dequant_rows<F, T::G, OUT, false, T::NTS, 1, ARITH, false>), dim3(groups_per_row, (uint32_t)rows), dim3(64), 0, s,
+                           static_cast<const uint8_t*>(packed), indices + first, static_cast<uint8_t*>(out) + first * row_blocks * (uint64_t)F::BS * OUT_BYTES,
+                           n_rows, row_blocks, (uint64_t)groups_per_row);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 struct FormatEntry {
     int qtype, block_size, type_size;
     int group[3][3];       // blocks per group, [compute dtype][out dtype] (the team shape may differ per mode)
     one_fn one[3][3];      // [compute dtype][out dtype]
     many_fn many[3][3];
+    rows_fn rows[3][3];
 };
 
 #define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
@@ -197,7 +217,8 @@ struct FormatEntry {
     FormatEntry {                                                                              \
         F::ID, F::BS, F::TS, {GGQ_GROUPS(F, AR_F16), GGQ_GROUPS(F, AR_BF16), GGQ_GROUPS(F, AR_F32)},     \
         {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
-        {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)}    \
+        {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)},   \
+        {GGQ_ROW(run_rows, F, AR_F16), GGQ_ROW(run_rows, F, AR_BF16), GGQ_ROW(run_rows, F, AR_F32)}    \
     }
 
 const FormatEntry FORMATS[] = {
@@ -253,7 +274,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 3; }
+int ggq_abi_version(void) { return 4; }
 
 int ggq_supported(int qtype) { return find_format(qtype) ? 1 : 0; }
 
@@ -299,6 +320,20 @@ int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int
 int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream)
 {
     return ggq_dequant(qtype, packed, n_blocks, out_f16, GGQ_F16, GGQ_F16, hip_stream);
+}
+
+int ggq_dequant_rows(int qtype, const void* packed, uint64_t n_rows, uint32_t row_blocks, const int64_t* indices, uint64_t n_indices, void* out,
+                     int compute_dtype, int out_dtype, void* hip_stream)
+{
+    const FormatEntry* f = find_format(qtype);
+    if (!f) return GGQ_ERR_QTYPE;
+    if (out_dtype < 0 || out_dtype > 2 || compute_dtype < 0 || compute_dtype > 2) return GGQ_ERR_ARG;
+    if (n_indices == 0 || row_blocks == 0) return GGQ_OK;
+    if (n_rows == 0 || !packed || !indices || !out) return GGQ_ERR_ARG;
+    // every row must start 16-byte aligned, like a tensor of its own
+    if (!aligned16(packed) || !aligned16(out) || ((uint64_t)row_blocks * (uint64_t)f->type_size) % 16 != 0) return GGQ_ERR_ALIGN;
+    const hipError_t e = f->rows[compute_dtype][out_dtype](packed, indices, out, n_rows, row_blocks, n_indices, static_cast<hipStream_t>(hip_stream));
+    return e == hipSuccess ? GGQ_OK : hip_fail(e);
 }
 
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)

@@ -765,4 +765,22 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
     });
 }
 
+// rows of ONE packed table picked by an index vector (the embedding lookup, reference ops.py:251-260): output row t = table row
+// indices[t].  The same engine with a different locate -- grid.y walks the output rows (no integer division on the device: its
+// expansion goes through fp32 multiply-adds, which the build's FMA guard rightly refuses), grid.x the groups of one row; the
+// index is a wave-uniform scalar load; indices outside [0, n_rows) are clamped (F.embedding asserts on them).
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
+__global__ __launch_bounds__(WAVES * 64) void dequant_rows(const uint8_t* __restrict__ packed, const int64_t* __restrict__ indices, uint8_t* __restrict__ out,
+                                                           uint64_t n_rows, uint32_t row_blocks, uint64_t groups_per_row)
+{
+    constexpr uint64_t OUT_BYTES = (OUT == OUT_F32) ? 4 : 2;
+    const uint64_t t = blockIdx.y;
+    Engine<F, G, OUT, NTL, NTS, WAVES, 0, false, -1, 1, ARITH, COOP>::run(groups_per_row, 0u, [&](uint64_t g) {
+        int64_t row = indices[t];
+        row = row < 0 ? 0 : (row >= (int64_t)n_rows ? (int64_t)n_rows - 1 : row);
+        return Work{(gcptr)packed + (uint64_t)row * row_blocks * (uint64_t)F::TS, (gptr)out + t * row_blocks * (uint64_t)F::BS * OUT_BYTES,
+                    (uint64_t)row_blocks, g};
+    });
+}
+
 }  // namespace ggq

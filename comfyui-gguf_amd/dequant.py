@@ -224,6 +224,45 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
                          "(the reference falls back to gguf's numpy dequantize here, dequant.py:24-28)")
 
 
+def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
+    """``F.embedding(indices, dequantize_tensor(tensor, dtype, dequant_dtype))`` without unpacking the whole table: only the
+    rows ``indices`` names are dequantized (include/ggq.h ``ggq_dequant_rows``), bit-identical values.  What
+    ``GGMLOps.Embedding.forward_ggml_cast_weights`` computes (ops.py:251-260) in two steps.  ``tensor``: quantized, logical
+    shape (n_rows, cols), GPU-resident; ``indices``: integer tensor on the same device; result: indices.shape + (cols,).
+    Raises GGQUnsupported for anything else (the caller keeps dequantize_tensor + F.embedding)."""
+    qtype = getattr(tensor, "tensor_type", None)
+    key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
+    if key not in _HIP_TABLE:
+        raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r}")
+    shape = tuple(getattr(tensor, "tensor_shape", ()))
+    dequant_dtype = dtype if dequant_dtype == "target" else dequant_dtype
+    compute_code = _check_compute(dequant_dtype)
+    out_dtype = _COMPUTE_TORCH[dequant_dtype] if dtype is None else dtype
+    if len(shape) != 2 or out_dtype not in _OUT_CODE:
+        raise GGQUnsupported("row lookup: a 2-D table and an fp16 / bf16 / fp32 result")
+    qid, block_size, type_size = _HIP_TABLE[key]
+    n_rows, cols = shape
+    if cols % block_size or (cols // block_size * type_size) % 16:
+        raise GGQUnsupported("row lookup: every row must be whole blocks and start 16-byte aligned")
+    data = tensor if isinstance(tensor, torch.Tensor) else tensor.data
+    with _NoTorchFunction():
+        if not data.is_cuda or not indices.is_cuda or indices.dtype not in (torch.int64, torch.int32):
+            raise GGQUnsupported("row lookup: GPU-resident table and int32 / int64 indices on the GPU")
+        if data.dtype is not torch.uint8 or not data.is_contiguous() or data.data_ptr() & 15:
+            data = _as_bytes(data)
+        if data.numel() != n_rows * (cols // block_size) * type_size:
+            raise GGQUnsupported("row lookup: packed bytes do not match the logical shape")
+        idx = indices.reshape(-1).to(torch.int64).contiguous()
+        out = torch.empty(tuple(indices.shape) + (cols,), dtype=out_dtype, device=data.device)
+        if idx.numel():
+            index = data.device.index
+            with torch.cuda.device(index):
+                rc = _native.lib().ggq_dequant_rows(qid, data.data_ptr(), n_rows, cols // block_size, idx.data_ptr(), idx.numel(), out.data_ptr(),
+                                                    compute_code, _OUT_CODE[out_dtype], _raw_stream(index))
+            _native.check(rc, "ggq_dequant_rows")
+    return out
+
+
 # ---- dequantize_functions: the reference's per-format block functions (dequant.py:287-301) --------
 
 def dequantize_blocks_BF16(blocks, block_size, type_size, dtype=None):

@@ -18,6 +18,12 @@ in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM 
 (reference ops.py:242-244): inputs of one to four rows (FLUX's modulation layers) go through the fused dequantize +
 linear kernel (fused.py) when weight and input qualify, everything else -- LoRA-patched weights included -- through the
 reference's method.  Opt-in because the result matches F.linear up to fp32 summation order, not bit for bit.
+
+``gather_embedding`` (or ``GGQ_GATHER_EMBEDDING=1``; needs ``ref_ops``) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights``
+(reference ops.py:251-260): instead of dequantizing the whole table and then gathering, only the rows the token ids name are
+unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense table (a 152 k x 3584 vocabulary is 1.1 GB).
+Tables the kernel does not take (CPU, F16 / F32 storage, rows not 16-byte aligned, ``max_norm`` set, LoRA patches) keep the
+reference's method.
 """
 import os
 
@@ -28,7 +34,7 @@ from . import dequant as _hip
 _installed = {}
 
 
-def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None):
+def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -77,8 +83,36 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         if ref_ops is None:
             raise ValueError("fused_small_m patches GGMLOps.Linear: pass ref_ops")
         patched.append(_fuse_small_m(ref_ops.GGMLOps.Linear, unsupported))
+    if gather_embedding is None:
+        gather_embedding = os.environ.get("GGQ_GATHER_EMBEDDING", "0") not in ("", "0")
+    if gather_embedding:
+        if ref_ops is None:
+            raise ValueError("gather_embedding patches GGMLOps.Embedding: pass ref_ops")
+        patched.append(_gather_embedding(ref_ops.GGMLOps.Embedding, unsupported))
     _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache}
     return orig
+
+
+def _gather_embedding(embedding_cls, unsupported):
+    """Wrap ``embedding_cls.forward_ggml_cast_weights``; returns the (owner, name, original) record uninstall() restores."""
+    from .dequant import dequantize_rows
+    reference_forward = embedding_cls.forward_ggml_cast_weights
+
+    def forward_ggml_cast_weights(self, input, out_dtype=None):
+        weight = self.weight
+        if (input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
+                and not getattr(weight, "patches", None)):
+            # the table's dtype the reference's way: out_dtype, else what cast_bias_weight(self, ...) falls back to (ops.py:196-197)
+            table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
+            try:
+                return dequantize_rows(weight.to(input.device), input, table_dtype, self.dequant_dtype).to(dtype=out_dtype)
+            except unsupported:
+                pass
+        return reference_forward(self, input, out_dtype)
+
+    forward_ggml_cast_weights.__wrapped__ = reference_forward
+    embedding_cls.forward_ggml_cast_weights = forward_ggml_cast_weights
+    return (embedding_cls, "forward_ggml_cast_weights", reference_forward)
 
 
 def _fuse_small_m(linear_cls, unsupported):

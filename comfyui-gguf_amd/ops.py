@@ -125,10 +125,21 @@ class GGMLEmbedding(GGMLLayer):
         super().__init__(weight, None)
         self.padding_idx = padding_idx
 
+    gather_rows = True                             # quantized table on the GPU: unpack only the rows asked for (bit-identical)
+
     def forward(self, input, out_dtype=None):
         output_dtype = out_dtype
         if self.weight.dtype == torch.float16 or self.weight.dtype == torch.bfloat16:
             out_dtype = None
+        if self.gather_rows and is_quantized(self.weight) and input.is_cuda and not getattr(self.weight, "patches", None):
+            from .dequant import GGQUnsupported, dequantize_rows
+            try:
+                # cast_bias_weight(self, dtype=None) falls back to getattr(self, "dtype", float32) (ops.py:196-197): same here
+                table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
+                rows = dequantize_rows(self.weight.to(input.device), input, table_dtype, self.dequant_dtype)
+                return rows.to(dtype=output_dtype)
+            except GGQUnsupported:
+                pass
         weight, _ = self.cast_bias_weight(self, device=input.device, dtype=out_dtype)
         return torch.nn.functional.embedding(input, weight, self.padding_idx).to(dtype=output_dtype)
 

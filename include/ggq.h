@@ -86,6 +86,17 @@ int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int
 /* Same with compute_dtype = out_dtype = GGQ_F16 (the stock node: dequantize(data, qtype, oshape)). */
 int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_f16, void* hip_stream);
 
+/* ---- rows of one table (the embedding lookup) ------------------------------------------------------------------- */
+
+/* out[i, :] = dequantized row indices[i] of a packed (n_rows x cols) table, cols = row_blocks * block_size; out is
+ * (n_indices x cols) of out_dtype.  Replaces: GGMLOps.Embedding.forward_ggml_cast_weights (ops.py:251-260), which
+ * dequantizes the WHOLE table (dequantize_tensor, ops.py:177) and then gathers with F.embedding: the values are the same bit
+ * for bit, but only the rows asked for are unpacked -- a 152 k x 3584 table costs 1.1 GB of transient dense weight the
+ * reference's way.  indices: device, int64, n_indices of them; an index outside [0, n_rows) is clamped (F.embedding asserts).
+ * GGQ_ERR_ALIGN if a row's packed bytes (row_blocks * type_size) are not a multiple of 16: the caller keeps the two-step path. */
+int ggq_dequant_rows(int qtype, const void* packed, uint64_t n_rows, uint32_t row_blocks, const int64_t* indices, uint64_t n_indices,
+                     void* out, int compute_dtype, int out_dtype, void* hip_stream);
+
 /* ---- many tensors, one call (the weight set of a model) ------------------------------------- */
 
 /* One entry per tensor.  Replaces: one dequantize_tensor() call per layer (ops.py:177). */

@@ -273,7 +273,13 @@ def _fake_comfy():
             pass
 
         class Embedding(torch.nn.Embedding, CastWeightBiasOp):
-            pass
+            bias = None                                    # as comfy.ops.disable_weight_init.Embedding
+
+            def forward_comfy_cast_weights(self, input, out_dtype=None):
+                return torch.nn.functional.embedding(input, self.weight.to(out_dtype), self.padding_idx)
+
+            def forward(self, *a, **k):
+                return self.forward_comfy_cast_weights(*a, **k)
 
         class LayerNorm(torch.nn.LayerNorm, CastWeightBiasOp):
             pass
@@ -352,3 +358,17 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
     with pytest.raises(ValueError):
         pkg.install.install(rd, fused_small_m=True)
     pkg.install.uninstall(rd)
+    # with the opt-in row lookup: a CPU table is not the kernel's business -> the reference's method, same result
+    table = ro.GGMLTensor(torch.from_numpy(pkg.synth.make_tensor_bytes(Q.Q8_0, (16, 256), seed=5).copy()), tensor_type=Q.Q8_0, tensor_shape=torch.Size((16, 256)))
+    emb = ro.GGMLOps.Embedding(16, 256)
+    emb.weight = torch.nn.Parameter(table, requires_grad=False)
+    ids = torch.tensor([[0, 3, 15, 3]])
+    ref_rows = emb(ids, out_dtype=torch.float32)
+    ref_emb_forward = ro.GGMLOps.Embedding.forward_ggml_cast_weights
+    pkg.install.install(rd, ro, gather_embedding=True)
+    try:
+        assert ro.GGMLOps.Embedding.forward_ggml_cast_weights is not ref_emb_forward
+        assert torch.equal(emb(ids, out_dtype=torch.float32), ref_rows)
+    finally:
+        pkg.install.uninstall(rd)
+    assert ro.GGMLOps.Embedding.forward_ggml_cast_weights is ref_emb_forward
