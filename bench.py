@@ -36,7 +36,10 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's intra-node transport); the launcher normally exports it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
