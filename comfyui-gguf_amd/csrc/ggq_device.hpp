@@ -586,7 +586,10 @@ GGQ_DEV void store_throttle()
     if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
 }
 
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
+// SKEW: the tensor's base pointer itself may be only 2-byte aligned (a row inside a packed table): the misalignment of every
+// group start is then taken from the ADDRESS, not from the offset inside the tensor.
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
+          bool SKEW = false>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -594,7 +597,7 @@ struct Engine {
     // A group starts 16-B aligned when GROUP_BYTES % 16 == 0 (any G that is a multiple of 8);
     // otherwise its start is only MISALIGN_STEP-aligned and the wave loads from the aligned
     // address below it, keeping the same byte offset inside its LDS slice.
-    static constexpr bool ALIGNED = GROUP_BYTES % 16 == 0;
+    static constexpr bool ALIGNED = GROUP_BYTES % 16 == 0 && !SKEW;
     static constexpr int UNITS = (GROUP_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;   // 16-B load units per group (max)
     // TEAM = the threads that own one group: a wavefront, or (COOP) the whole workgroup -- then every wave stores ONE
     // 1-KiB row instead of four back to back, which the memory system takes 6 % faster (tests/microbench `fillrows`).
@@ -607,6 +610,7 @@ struct Engine {
     static constexpr int THREADS = WAVES * 64;
     static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
     static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
+    static_assert(!SKEW || (F::TS % F::LDS_ALIGN == 0 && !DIRECT), "a row start is a multiple of the block size only");
     static_assert((CHUNKS * PIECES) % TEAM == 0, "a group must be a whole number of 1 KiB store rows per wave");
     static_assert(!(COOP && DIRECT) && !(COOP && R != 1), "COOP is the LDS-staged single-pass engine");
 
@@ -622,7 +626,7 @@ struct Engine {
     GGQ_DEV static void body(uint8_t* slice, const Work& w, int lane)      // lane = index inside the team
     {
         const uint64_t off = w.lg * (uint64_t)GROUP_BYTES;
-        const uint32_t a = ALIGNED ? 0u : ((uint32_t)off & 15u);            // wave-uniform
+        const uint32_t a = ALIGNED ? 0u : ((uint32_t)((SKEW ? (uint64_t)w.packed : 0ull) + off) & 15u);   // wave-uniform
         const gcptr base = w.packed + off - a;
         uint32_t valid = a + (uint32_t)GROUP_BYTES;
         if constexpr (!FULL) {
@@ -768,14 +772,15 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
 // rows of ONE packed table picked by an index vector (the embedding lookup, reference ops.py:251-260): output row t = table row
 // indices[t].  The same engine with a different locate -- grid.y walks the output rows (no integer division on the device: its
 // expansion goes through fp32 multiply-adds, which the build's FMA guard rightly refuses), grid.x the groups of one row; the
-// index is a wave-uniform scalar load; indices outside [0, n_rows) are clamped (F.embedding asserts on them).
+// index is a wave-uniform scalar load; indices outside [0, n_rows) are clamped (F.embedding asserts on them).  A row starts
+// wherever its blocks do (2-byte aligned at worst): the SKEW engine loads from the aligned address below it.
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_rows(const uint8_t* __restrict__ packed, const int64_t* __restrict__ indices, uint8_t* __restrict__ out,
                                                            uint64_t n_rows, uint32_t row_blocks, uint64_t groups_per_row)
 {
     constexpr uint64_t OUT_BYTES = (OUT == OUT_F32) ? 4 : 2;
     const uint64_t t = blockIdx.y;
-    Engine<F, G, OUT, NTL, NTS, WAVES, 0, false, -1, 1, ARITH, COOP>::run(groups_per_row, 0u, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, 0, false, -1, 1, ARITH, COOP, true>::run(groups_per_row, 0u, [&](uint64_t g) {
         int64_t row = indices[t];
         row = row < 0 ? 0 : (row >= (int64_t)n_rows ? (int64_t)n_rows - 1 : row);
         return Work{(gcptr)packed + (uint64_t)row * row_blocks * (uint64_t)F::TS, (gptr)out + t * row_blocks * (uint64_t)F::BS * OUT_BYTES,

@@ -242,8 +242,8 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
         raise GGQUnsupported("row lookup: a 2-D table and an fp16 / bf16 / fp32 result")
     qid, block_size, type_size = _HIP_TABLE[key]
     n_rows, cols = shape
-    if cols % block_size or (cols // block_size * type_size) % 16:
-        raise GGQUnsupported("row lookup: every row must be whole blocks and start 16-byte aligned")
+    if cols % block_size:
+        raise GGQUnsupported("row lookup: every row must be whole blocks")
     data = tensor if isinstance(tensor, torch.Tensor) else tensor.data
     with _NoTorchFunction():
         if not data.is_cuda or not indices.is_cuda or indices.dtype not in (torch.int64, torch.int32):

@@ -22,7 +22,7 @@ reference's method.  Opt-in because the result matches F.linear up to fp32 summa
 ``gather_embedding`` (or ``GGQ_GATHER_EMBEDDING=1``; needs ``ref_ops``) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights``
 (reference ops.py:251-260): instead of dequantizing the whole table and then gathering, only the rows the token ids name are
 unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense table (a 152 k x 3584 vocabulary is 1.1 GB).
-Tables the kernel does not take (CPU, F16 / F32 storage, rows not 16-byte aligned, ``max_norm`` set, LoRA patches) keep the
+Tables the kernel does not take (CPU, F16 / F32 storage, ``max_norm`` set, LoRA patches) keep the
 reference's method.
 """
 import os

@@ -93,7 +93,8 @@ int ggq_dequant_f16(int qtype, const void* packed, uint64_t n_blocks, void* out_
  * dequantizes the WHOLE table (dequantize_tensor, ops.py:177) and then gathers with F.embedding: the values are the same bit
  * for bit, but only the rows asked for are unpacked -- a 152 k x 3584 table costs 1.1 GB of transient dense weight the
  * reference's way.  indices: device, int64, n_indices of them; an index outside [0, n_rows) is clamped (F.embedding asserts).
- * GGQ_ERR_ALIGN if a row's packed bytes (row_blocks * type_size) are not a multiple of 16: the caller keeps the two-step path. */
+ * packed and out 16-byte aligned; the rows themselves may start at any block boundary (row_blocks * type_size need not be a
+ * multiple of 16). */
 int ggq_dequant_rows(int qtype, const void* packed, uint64_t n_rows, uint32_t row_blocks, const int64_t* indices, uint64_t n_indices,
                      void* out, int compute_dtype, int out_dtype, void* hip_stream);
 

@@ -36,7 +36,9 @@ def test_rows_equal_the_oracle_rows_in_every_mode(pkg, name):
     q = pkg.qtypes.Q[name]
     bs, _ = pkg.qtypes.block_geometry(q)
     g = torch.Generator().manual_seed(int(q))
-    for blocks_per_row in (8, 24) + ((40,) if bs == 32 else ()):              # 40 x 32: a partial group inside every row
+    # 8 / 24: whole groups; 40 x 32: a partial group inside every row; 1, 3, 14 (3584-wide K-quant rows), 67: rows that start
+    # at 2-, 4- or 8-byte aligned addresses only and end inside a group
+    for blocks_per_row in (8, 24, 1, 3, 14, 67) + ((40,) if bs == 32 else ()):
         cols, n_rows = blocks_per_row * bs, 37
         blocks, table = _table(pkg, q, n_rows, cols, seed=100 + blocks_per_row, mode="signed" if blocks_per_row == 24 else "nominal")
         idx = torch.randint(0, n_rows, (3, 19), generator=g)
@@ -78,12 +80,15 @@ def test_rows_match_the_two_step_path_of_the_layer(pkg):
 def test_rows_limits(pkg):
     Q = pkg.qtypes.Q
     U = pkg.dequant.GGQUnsupported
-    _, narrow = _table(pkg, Q.Q2_K, 16, 256, seed=1)                           # 84-byte rows: not 16-byte aligned
     ids = torch.zeros(4, dtype=torch.int64, device=DEV)
+    ragged = pkg.ops.GGMLTensor(torch.zeros(16 * 84 + 84, dtype=torch.uint8, device=DEV), tensor_type=Q.Q2_K, tensor_shape=(16, 256))
     with pytest.raises(U):
-        pkg.dequant.dequantize_rows(narrow, ids, torch.float16)
-    emb = pkg.ops.GGMLEmbedding(narrow)                                        # ... so the layer takes the two-step path by itself
-    assert torch.equal(emb(ids, out_dtype=torch.float16), pkg.dequant.dequantize_tensor(narrow, torch.float16)[ids])
+        pkg.dequant.dequantize_rows(ragged, ids, torch.float16)                # packed bytes do not match the logical shape
+    f16_table = pkg.ops.GGMLTensor(torch.zeros(16, 256, dtype=torch.float16, device=DEV), tensor_type=Q.F16, tensor_shape=(16, 256))
+    with pytest.raises(U):
+        pkg.dequant.dequantize_rows(f16_table, ids, torch.float16)             # stored dense: nothing to unpack
+    emb = pkg.ops.GGMLEmbedding(f16_table)                                     # ... so the layer takes the two-step path by itself
+    assert torch.equal(emb(ids, out_dtype=torch.float16), f16_table.as_subclass(torch.Tensor)[ids])
     _, table = _table(pkg, Q.Q8_0, 8, 256, seed=2)
     with pytest.raises(U):
         pkg.dequant.dequantize_rows(table, ids.cpu(), torch.float16)           # indices on the CPU
@@ -102,7 +107,7 @@ def test_rows_limits(pkg):
     assert L.ggq_dequant_rows(int(Q.Q8_0), None, 8, 8, None, 0, None, 0, 0, None) == nat.GGQ_OK           # nothing to do
     assert L.ggq_dequant_rows(999, table.data_ptr(), 8, 8, ids.data_ptr(), 4, got.data_ptr(), 0, 0, None) == nat.GGQ_ERR_QTYPE
     assert L.ggq_dequant_rows(int(Q.Q8_0), table.data_ptr(), 8, 8, ids.data_ptr(), 4, got.data_ptr(), 0, 5, None) == nat.GGQ_ERR_ARG
-    assert L.ggq_dequant_rows(int(Q.Q8_0), table.data_ptr(), 8, 1, ids.data_ptr(), 4, got.data_ptr(), 0, 0, None) == nat.GGQ_ERR_ALIGN
+    assert L.ggq_dequant_rows(int(Q.Q8_0), table.data_ptr() + 2, 8, 8, ids.data_ptr(), 4, got.data_ptr(), 0, 0, None) == nat.GGQ_ERR_ALIGN
 
 
 def test_install_gather_embedding_wraps_the_embedding_forward(pkg):
