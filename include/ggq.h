@@ -38,6 +38,7 @@ typedef enum ggq_status {
     GGQ_ERR_ARG = 3,     /* NULL pointer with n_blocks > 0, bad compute/out dtype, bad descriptor table */
     GGQ_ERR_HIP = 4,     /* a HIP runtime call failed; ggq_last_hip_error() has the hipError_t */
     GGQ_ERR_NOMEM = 5    /* host or device allocation for a plan failed */
+    /* 6, 7: GGQ_ERR_IO, GGQ_ERR_FORMAT of the GGUF reader (ggq_gguf.h) */
 } ggq_status;
 
 /* Floating-point dtypes, used for two independent choices of dequantize_tensor (dequant.py:15-23):
@@ -49,10 +50,6 @@ typedef enum ggq_status {
  *                  to the block function's result (dequant.py:23), fused into the store -- same values
  *                  as dequantize(..., dtype=compute_dtype).to(out_dtype), one pass over memory. */
 typedef enum ggq_dtype { GGQ_F16 = 0, GGQ_BF16 = 1, GGQ_F32 = 2 } ggq_dtype;
-/* older spellings of the out_dtype values */
-#define GGQ_OUT_F16 GGQ_F16
-#define GGQ_OUT_BF16 GGQ_BF16
-#define GGQ_OUT_F32 GGQ_F32
 
 /* ---- queries ------------------------------------------------------------------------------- */
 

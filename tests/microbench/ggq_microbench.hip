@@ -851,7 +851,7 @@ static void formats()
     for (const QT& q : QTS) {
         Pool P = make_pool(q, 64);
         std::vector<ggq_desc> descs;
-        for (auto& d : P.descs) descs.push_back(ggq_desc{q.id, GGQ_OUT_F16, d.packed, d.out, d.n_blocks});
+        for (auto& d : P.descs) descs.push_back(ggq_desc{q.id, GGQ_F16, d.packed, d.out, d.n_blocks});
         ggq_plan* plan = nullptr;
         int rc = ggq_plan_create(descs.data(), (uint32_t)descs.size(), &plan);
         if (rc) { printf("FMT %s: plan_create rc=%d\n", q.name, rc); continue; }
@@ -885,7 +885,7 @@ static void pmc_sequence()
     for (int qi : {7, 0, 9, 4, 2, 5, 6}) {
         Pool P = make_pool(QTS[qi], 64);
         std::vector<ggq_desc> descs;
-        for (auto& d : P.descs) descs.push_back(ggq_desc{QTS[qi].id, GGQ_OUT_F16, d.packed, d.out, d.n_blocks});
+        for (auto& d : P.descs) descs.push_back(ggq_desc{QTS[qi].id, GGQ_F16, d.packed, d.out, d.n_blocks});
         ggq_plan* plan = nullptr;
         if (ggq_plan_create(descs.data(), (uint32_t)descs.size(), &plan)) { printf("plan_create failed\n"); continue; }
         printf("PMC %s pool: packed read %llu B + fp16 write %llu B = %llu B per launch\n", QTS[qi].name, (unsigned long long)(P.elements / P.bs * P.ts),
