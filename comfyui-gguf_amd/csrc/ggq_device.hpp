@@ -10,7 +10,8 @@
 //
 // Shape of the work (HBM-bound byte unpack, no MFMA -- there is no contraction here):
 //   * unit of work = a GROUP of G consecutive blocks, owned by a TEAM: one wavefront (default), or the
-//     2 / 4 wavefronts of a workgroup together (COOP; ten formats in the fp16 arithmetic mode);
+//     4 wavefronts of a workgroup together (COOP; most formats in the fp16 arithmetic mode -- the host picks the team
+//     shape per (format, arithmetic, output dtype, launch size), ggq_capi.hip);
 //   * the team copies the group's packed bytes HBM -> VGPR -> its LDS slice with coalesced
 //     16 B/lane loads (a group starts 16-B aligned because 8*type_size % 16 == 0 for every ggml
 //     block format);
