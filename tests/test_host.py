@@ -142,6 +142,18 @@ def test_dispatch_and_error_behaviour_on_cpu(pkg, golden_dir):
     odd = _Carrier(torch.zeros(66, dtype=torch.uint8), Q.IQ2_XXS, torch.Size((256,)))
     with pytest.raises(dq.GGQUnsupported, match="IQ2_XXS"):
         dq.dequantize_tensor(odd, torch.float16)
+    # the row lookup (embedding caller) has no CPU path either, and says so before touching the library
+    ids = torch.tensor([0, 0])
+    with pytest.raises(dq.GGQUnsupported, match="GPU"):
+        dq.dequantize_rows(q, ids, torch.float16)
+    with pytest.raises(dq.GGQUnsupported, match="2-D"):
+        dq.dequantize_rows(_Carrier(torch.zeros(144, dtype=torch.uint8), Q.Q4_K, torch.Size((256,))), ids, torch.float16)
+    with pytest.raises(dq.GGQUnsupported, match="whole blocks"):
+        dq.dequantize_rows(_Carrier(torch.zeros(144, dtype=torch.uint8), Q.Q4_K, torch.Size((2, 128))), ids, torch.float16)
+    with pytest.raises(dq.GGQUnsupported, match="IQ2_XXS"):
+        dq.dequantize_rows(odd, ids, torch.float16)
+    emb = pkg.ops.GGMLEmbedding(pkg.ops.GGMLTensor(torch.zeros(2, 4), tensor_type=Q.F32, tensor_shape=(2, 4)))
+    assert emb(ids, out_dtype=torch.float32).shape == (2, 4)             # CPU / dense table: plain F.embedding
     assert set(dq.dequantize_functions) == set(pkg.qtypes.HIP_QTYPES) | {Q.BF16}
     assert dq.dequantize_functions[Q.Q6_K].__name__ == "dequantize_blocks_Q6_K"
     with pytest.raises(ValueError):
