@@ -77,16 +77,22 @@ GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
 // The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
 // two chunks per thread the coop teams then lose 1-7 % on every format but the two with the lightest arithmetic per
 // packed byte (bench.py per-mode table, solo vs coop builds on one box): those modes run the solo shape.
+#ifdef GGQ_COOP_ALL_MODES     /* A/B builds only: the workgroup teams in every arithmetic mode and for every output dtype */
+template <class F> struct CoopInAllModes { static constexpr bool V = true; };
+#else
 template <class F> struct CoopInAllModes { static constexpr bool V = false; };
 template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };     // +7...12 % in every mode
 template <> struct CoopInAllModes<FmtQ4_1> { static constexpr bool V = true; };     // +4 % fp32 arithmetic, level in bf16
+#endif
 // ... and so does the bf16 output cast (1.5 more conversions per element, the production case: FLUX computes in bf16) for the
 // formats with the heavier decode.  Same-box alternation of two builds over all formats and output dtypes
 // (tools/mode_table.py, profiles/r01_mode_table_coop_vs_solo_cast_outputs.json), solo vs coop with bf16 output: Q5_K +5.5 %,
 // Q4_K +4.0 %, Q2_K +4.0 %, IQ4_NL +3.8 %, IQ4_XS +3.0 %; level for Q4_0 / Q5_0; Q4_1 -2.6 %, Q5_1 -2.1 %, Q8_0 -4.2 % (stay coop).
 // fp32 output keeps the coop shape everywhere (solo: -1...-9 %, level for Q5_0 / Q5_K / IQ4_XS).
-#ifdef GGQ_SOLO_CAST_OUT      /* A/B builds only: one-wave teams whenever the output is not fp16 */
+#if defined(GGQ_SOLO_CAST_OUT)      /* A/B builds only: one-wave teams whenever the output is not fp16 */
 template <class F, int OUT> struct CoopForOut { static constexpr bool V = OUT == OUT_F16; };
+#elif defined(GGQ_COOP_ALL_MODES)
+template <class F, int OUT> struct CoopForOut { static constexpr bool V = true; };
 #else
 template <class F, int OUT> struct CoopForOut { static constexpr bool V = true; };
 template <> struct CoopForOut<FmtQ2_K, OUT_BF16> { static constexpr bool V = false; };
@@ -95,8 +101,29 @@ template <> struct CoopForOut<FmtQ5_K, OUT_BF16> { static constexpr bool V = fal
 template <> struct CoopForOut<FmtIQ4_NL, OUT_BF16> { static constexpr bool V = false; };
 template <> struct CoopForOut<FmtIQ4_XS, OUT_BF16> { static constexpr bool V = false; };
 #endif
-template <class F, int ARITH, int OUT> struct TuneFor
-    : std::conditional<!Tune<F>::COOP || ((ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V), Tune<F>, TuneSolo<F>>::type {};
+// The rule so far -- coop for the fp16 arithmetic (minus the bf16-output exceptions), solo for the other arithmetic modes except
+// Q8_0 / Q4_1 -- and the cells where an all-coop against an all-solo build, alternated twice on one box over all 12 x 9 cells
+// (profiles/r01_mode_table_all_coop_vs_all_solo.json), says otherwise by more than 1.5 % in both alternations:
+template <class F, int ARITH, int OUT> struct UseCoop {
+    static constexpr bool V = (ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V;
+};
+#if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES)
+#define GGQ_TEAM(F, AR, OUT_, COOP_) template <> struct UseCoop<F, AR, OUT_> { static constexpr bool V = COOP_; }
+GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F16, false);     // coop -4.1 %  (bf16 arithmetic: -1.1 % with the other two outputs, taken along)
+GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_BF16, false);
+GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F32, false);
+GGQ_TEAM(FmtQ5_1, AR_BF16, OUT_BF16, true);     // coop +1.8 %
+GGQ_TEAM(FmtQ5_1, AR_BF16, OUT_F32, true);      //      +3.3 %
+GGQ_TEAM(FmtQ5_1, AR_F32, OUT_F16, true);       //      +3.6 %
+GGQ_TEAM(FmtQ5_1, AR_F32, OUT_BF16, true);      //      +4.5 %
+GGQ_TEAM(FmtQ5_1, AR_F32, OUT_F32, true);       //      +6.1 %
+GGQ_TEAM(FmtQ4_K, AR_BF16, OUT_F32, true);      //      +2.8 %  (fp32 output doubles the store rows per wave: coop halves them again)
+GGQ_TEAM(FmtQ5_K, AR_BF16, OUT_F32, true);      //      +6.8 %
+GGQ_TEAM(FmtQ5_K, AR_F32, OUT_F32, true);       //      +2.6 %
+GGQ_TEAM(FmtIQ4_NL, AR_BF16, OUT_F32, true);    //      +1.8 %
+#undef GGQ_TEAM
+#endif
+template <class F, int ARITH, int OUT> struct TuneFor : std::conditional<!Tune<F>::COOP || UseCoop<F, ARITH, OUT>::V, Tune<F>, TuneSolo<F>>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 // ... for the one-wave teams.  The workgroup teams need the run mapping more (identity costs them 8 % on the 3 G-element pool)

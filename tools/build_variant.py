@@ -4,8 +4,9 @@
     python tools/build_variant.py -DGGQ_SOLO_ONLY -o gpurun_tmp_libs/libggq_solo.so
     gpurun -- 'for i in 1 2; do python bench.py ...; GGQ_HIP_LIB=$PWD/gpurun_tmp_libs/libggq_solo.so python bench.py ...; done'
 
-Defines the sources understand (csrc/ggq_capi.hip): GGQ_SOLO_ONLY (one-wave teams everywhere), GGQ_SOLO_CAST_OUT (one-wave
-teams whenever the output is not fp16), GGQ_CAST_SOLO_AT_LAYER_SIZE (... also for single layers).  The variant goes through
+Defines the sources understand (csrc/ggq_capi.hip): GGQ_SOLO_ONLY (one-wave teams everywhere), GGQ_COOP_ALL_MODES (workgroup
+teams everywhere), GGQ_SOLO_CAST_OUT (one-wave teams whenever the output is not fp16), GGQ_CAST_SOLO_AT_LAYER_SIZE (... also for
+single layers).  The variant goes through
 the same FMA guard as the shipped build.  Keep variants out of comfyui-gguf_amd/_lib/ and out of git (*.so is ignored)."""
 import argparse
 import importlib
