@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- dequant GB/s (packed in -> fp16 out) and % of HBM3E peak, per quant type.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--qtype Q4_K] [--pairs 8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--qtype Q4_K] [--pairs 64]
 
 A "step" is ONE pass of the hot path over the whole synthetic pool: a DequantPlan launch
 (include/ggq.h ggq_plan_launch) over `pairs` x (3072x3072 + 3072x12288) FLUX.1-dev-shaped
