@@ -3,8 +3,10 @@
 Parity note: the reference reads these files through the third-party gguf.GGUFReader (loader.py:55;
 gguf>=0.13.0, unpinned, absent from /root/reference and from this image), and ships no .gguf file and
 no loader test.  The parser is therefore pinned to the PUBLIC container layout: (a) a byte-for-byte
-hand-assembled file (below), (b) an independent pure-python writer (tests/gguf_writer.py); the loader
-mirror is checked against the behaviour read off loader.py:51-141 line by line."""
+hand-assembled file (below), (b) an independent pure-python writer (tests/gguf_writer.py).  The loader
+mirror -- everything done WITH the parsed file -- is pinned to the reference's own loader.py, executed verbatim on
+the same files behind a gguf-py-shaped adapter over our parser (last test; this container only), and
+otherwise checked against the behaviour read off loader.py:51-141."""
 import os
 import struct
 
@@ -282,3 +284,171 @@ def test_upload_argument_checks_without_a_gpu(pkg, gf, tmp_path):
         with pytest.raises(ValueError, match="AMD GPU"):
             f.upload("cpu")
     assert b"GGUF" in nat.lib().ggq_strerror(nat.GGQ_ERR_FORMAT)
+
+
+# ---------------------------------------------------------------- the reference's loader.py, run verbatim
+
+class _RefField:
+    """What loader.py reads off a gguf.ReaderField: .types, and the value through .parts[.data[i]] (loader.py:16-49)."""
+
+    def __init__(self, vt, field):
+        self.types = [vt(t) for t in field.types]
+        values = field.value if isinstance(field.value, tuple) else (field.value,)
+        if field.types[-1] == STRING:
+            self.parts = [np.frombuffer(v.encode("utf-8"), dtype=np.uint8) for v in values]
+        else:
+            self.parts = [np.array([v]) for v in values]
+        self.data = list(range(len(self.parts)))
+
+
+class _RefTensor:
+    def __init__(self, Q, t):
+        self.name, self.tensor_type, self.shape = t.name, t.tensor_type, np.array(t.shape, dtype=np.uint64)
+        raw = t.data.numpy()
+        self.data = raw.view(np.float32) if t.tensor_type == Q.F32 else raw.view(np.float16) if t.tensor_type == Q.F16 else raw
+
+
+def _reference_loader(pkg, monkeypatch):
+    """loader.py of /root/reference executed from its own source, with the two things it needs from outside stubbed: `comfy`
+    (test_host._fake_comfy) and `gguf` -- the enum / sizes stub of oracle/reference.py plus a GGUFReader that hands out OUR
+    parser's view of the file in gguf-py's attribute layout.  So the container parsing is not what this pins; everything the
+    loader does with it is."""
+    import enum
+    import importlib.util
+    import sys
+    import types
+    from oracle import reference
+    from test_host import _fake_comfy
+    reference.ensure_gguf()
+    stub = sys.modules["gguf"]
+    Q = pkg.qtypes.Q
+    vt = enum.IntEnum("GGUFValueType", dict(UINT8=0, INT8=1, UINT16=2, INT16=3, UINT32=4, INT32=5, FLOAT32=6, BOOL=7, STRING=8, ARRAY=9,
+                                            UINT64=10, INT64=11, FLOAT64=12))
+
+    class GGUFReader:
+        def __init__(self, path):
+            self._f = pkg.gguf_file.GGUFFile(str(path))
+            self.tensors = [_RefTensor(Q, t) for t in self._f.tensors]
+
+        def get_field(self, key):
+            f = self._f.get_field(key)
+            return None if f is None else _RefField(vt, f)
+
+    monkeypatch.setattr(stub, "GGUFValueType", vt, raising=False)
+    monkeypatch.setattr(stub, "GGUFReader", GGUFReader, raising=False)
+    for k, v in _fake_comfy().items():
+        monkeypatch.setitem(sys.modules, k, v)
+    root = types.ModuleType("refldr")
+    root.__path__ = [reference.REFERENCE_DIR]
+    monkeypatch.setitem(sys.modules, "refldr", root)
+    tools = types.ModuleType("refldr.tools")
+    tools.__path__ = [os.path.join(reference.REFERENCE_DIR, "tools")]
+    monkeypatch.setitem(sys.modules, "refldr.tools", tools)
+    mods = {}
+    for name in ("dequant", "ops", "loader"):
+        spec = importlib.util.spec_from_file_location(f"refldr.{name}", os.path.join(reference.REFERENCE_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        monkeypatch.setitem(sys.modules, f"refldr.{name}", m)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["loader"]
+
+
+def _outcome(fn, *a, **k):
+    try:
+        return fn(*a, **k), None
+    except Exception as e:                                     # noqa: BLE001 -- the comparison is about which exception
+        return None, e
+
+
+def _same_state_dict(ours, theirs):
+    assert list(ours) == list(theirs)                          # same keys, same order
+    for key in ours:
+        a, b = ours[key], theirs[key]
+        ta, tb = getattr(a, "tensor_type", None), getattr(b, "tensor_type", None)        # None: a plain (dequantized) tensor
+        assert (None if ta is None else int(ta)) == (None if tb is None else int(tb)), key
+        assert tuple(a.shape) == tuple(b.shape) and a.dtype == b.dtype and tuple(a.size()) == tuple(b.size()), key
+        assert torch.equal(a.as_subclass(torch.Tensor), b.as_subclass(torch.Tensor)), key
+        assert bool(getattr(a, "is_largest_weight", False)) == bool(getattr(b, "is_largest_weight", False)), key
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")          # the reference's int(np.array([x])) under numpy 2
+@pytest.mark.skipif(not os.path.isfile("/root/reference/loader.py"), reason="/root/reference not present (GPU box)")
+def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch):
+    """gguf_sd_loader / get_field / get_list_field / get_orig_shape against the reference's own functions executed verbatim on
+    the same files: same state dicts (keys and their order, types, logical shapes, dtypes, bytes, largest-weight mark),
+    same architecture, same exception types and messages."""
+    Q, ours = pkg.qtypes.Q, pkg.loader
+    ref = _reference_loader(pkg, monkeypatch)
+    pre = "model.diffusion_model."
+    files = {
+        "flux": _model_file(pkg, tmp_path, extra_kv=[(f"comfy.gguf.orig_shape.{pre}x.conv.weight", ARRAY, [2, 3, 32], INT32),
+                                                     ("tokens", ARRAY, ["a", "bc", ""], STRING), ("merges", ARRAY, [3, 1, 2], INT32),
+                                                     ("pi", FLOAT32, 3.25), ("flag", BOOL, True), ("n", UINT64, 2 ** 40)])[0],
+        "sd3": _model_file(pkg, tmp_path, arch="sd3", prefix="")[0],
+        "t5": _model_file(pkg, tmp_path, arch="t5", prefix="")[0],
+        "mmproj": _model_file(pkg, tmp_path, arch="clip", prefix="", extra_kv=[("general.type", STRING, "mmproj")])[0],
+        "unknown": _model_file(pkg, tmp_path, arch="nonsense")[0],
+    }
+    w = GGUFWriter(arch=None)
+    w.add_tensor("a.weight", Q.F32, (4,), np.zeros(4, np.float32))
+    files["noarch"] = w.write(str(tmp_path / "noarch_live.gguf"))
+    w = GGUFWriter(arch="flux")
+    w.add("comfy.gguf.orig_shape.a.weight", ARRAY, [2, 2], INT64)
+    w.add_tensor("a.weight", Q.F32, (4,), np.zeros(4, np.float32))
+    files["badshape"] = w.write(str(tmp_path / "badshape_live.gguf"))
+    w = GGUFWriter(arch="flux")
+    w.add("general.architecture2", INT32, 7)
+    w.add_tensor("a.weight", Q.F32, (4,), np.zeros(4, np.float32))
+    files["plain"] = w.write(str(tmp_path / "plain_live.gguf"))
+
+    # files without architecture metadata (stable-diffusion.cpp exports, "pig"): the compatibility branch, which asks the reference's
+    # key-based detector (tools/convert.py detect_arch, control plane -- handed to our loader as a callable)
+    for label, arch, names in (("compat_flux", None, [(pre + "double_blocks.0.img_attn.proj.weight", Q.Q4_K, (8, 512))]),
+                               ("compat_pig", "pig", [("double_blocks.0.img_attn.proj.weight", Q.Q4_K, (8, 512))]),
+                               ("compat_sdxl", None, [("label_emb.0.0.weight", Q.F32, (4,)), ("input_blocks.4.1.proj_in.weight", Q.F16, (8, 4, 1, 1)),
+                                                      ("input_blocks.4.1.proj_out.weight", Q.F16, (8, 4, 1, 1)), ("mid.conv.weight", Q.F16, (2, 2, 1, 1))])):
+        w = GGUFWriter(arch=arch)
+        for i, (name, q, shape) in enumerate(names):
+            n = int(np.prod(shape))
+            data = np.arange(n, dtype=np.float32) if q == Q.F32 else np.arange(n, dtype=np.float16) if q == Q.F16 else pkg.synth.make_tensor_bytes(q, shape, seed=90 + i)
+            w.add_tensor(name, q, tuple(reversed(shape)), data)
+        files[label] = w.write(str(tmp_path / f"{label}.gguf"))
+    import importlib
+    detector = importlib.import_module("refldr.tools.convert").detect_arch
+
+    calls = [dict(), dict(return_arch=True), dict(handle_prefix=None), dict(handle_prefix="other."), dict(is_text_model=True, return_arch=True),
+             dict(handle_prefix="", return_arch=True)]
+    compared = 0
+    for label, path in files.items():
+        for kw in calls:
+            (got, e1), (want, e2) = _outcome(ours.gguf_sd_loader, path, detect_arch=detector, **kw), _outcome(ref.gguf_sd_loader, path, **kw)
+            assert (e1 is None) == (e2 is None), (label, kw, e1, e2)
+            if e2 is not None:
+                assert type(e1) is type(e2), (label, kw, e1, e2)
+                assert str(e1).split(", got ")[0] == str(e2).split(", got ")[0], (label, kw)     # enum reprs differ after "got"
+                compared += 1
+                continue
+            if kw.get("return_arch"):
+                assert got[1] == want[1], (label, kw)
+                got, want = got[0], want[0]
+            _same_state_dict(got, want)
+            compared += 1
+    assert compared == len(files) * len(calls)
+    # the metadata accessors on their own
+    a, b = pkg.gguf_file.GGUFFile(files["flux"]), sys_modules_reader(files["flux"])
+    for key, ftype in [("general.architecture", str), ("pi", float), ("flag", bool), ("n", int), ("merges", int), ("missing", int)]:
+        assert _outcome(ours.get_field, a, key, ftype)[0] == _outcome(ref.get_field, b, key, ftype)[0], key
+    for key, ftype in [("tokens", str), ("merges", int), ("merges", float), ("missing", str)]:
+        assert ours.get_list_field(a, key, ftype) == ref.get_list_field(b, key, ftype), key
+    for key, ftype in [("pi", str), ("general.architecture", dict)]:
+        (_, e1), (_, e2) = _outcome(ours.get_field, a, key, ftype), _outcome(ref.get_field, b, key, ftype)
+        assert type(e1) is type(e2) is TypeError and str(e1).split(", got ")[0] == str(e2).split(", got ")[0]
+    assert ours.get_orig_shape(a, pre + "x.conv.weight") == ref.get_orig_shape(b, pre + "x.conv.weight") == torch.Size((2, 3, 32))
+    assert ours.get_orig_shape(a, "nope") is ref.get_orig_shape(b, "nope") is None
+    a.close()
+
+
+def sys_modules_reader(path):
+    import sys
+    return sys.modules["gguf"].GGUFReader(path)
