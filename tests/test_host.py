@@ -192,6 +192,62 @@ def test_ggml_tensor_carries_attrs(pkg):
     assert t.copy_(torch.zeros(5, dtype=torch.uint8)) is None          # shape mismatch: logged and ignored (ops.py:70-75)
 
 
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_stand_in_layers_equal_the_reference_classes_live(pkg, monkeypatch):
+    """ops.py's GGMLTensor and the Linear / Embedding call chains against the reference's own classes (ops.py executed
+    verbatim over a fake `comfy`), same packed bytes, on CPU where both sides end in the reference's torch dequantizer."""
+    reference.ensure_gguf()
+    for k, v in _fake_comfy().items():
+        monkeypatch.setitem(sys.modules, k, v)
+    root = types.ModuleType("refops")
+    root.__path__ = [reference.REFERENCE_DIR]
+    monkeypatch.setitem(sys.modules, "refops", root)
+    mods = {}
+    for name in ("dequant", "ops"):
+        spec = importlib.util.spec_from_file_location(f"refops.{name}", os.path.join(reference.REFERENCE_DIR, f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        monkeypatch.setitem(sys.modules, f"refops.{name}", m)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    packed = torch.from_numpy(pkg.synth.make_tensor_bytes(Q.Q4_K, (2, 256), seed=3).copy())
+    ours = pkg.ops.GGMLTensor(packed.clone(), tensor_type=Q.Q4_K, tensor_shape=torch.Size((2, 256)), patches=[("p", "k")])
+    theirs = ro.GGMLTensor(packed.clone(), tensor_type=Q.Q4_K, tensor_shape=torch.Size((2, 256)), patches=[("p", "k")])
+
+    def view(t):
+        return (type(t).__name__, getattr(t, "tensor_type", None), tuple(t.shape), tuple(t.size()), t.dtype, list(getattr(t, "patches", [])))
+
+    for op in (lambda t: t, lambda t: t.to(torch.device("cpu")), lambda t: t.to(torch.uint8), lambda t: t.clone(), lambda t: t.detach(),
+               lambda t: t.new_empty((7,)), lambda t: t.new_empty((3, 2))):
+        assert view(op(ours)) == view(op(theirs))
+    assert (ours.clone() is ours) and (theirs.clone() is theirs) and (ours.detach() is ours)
+    assert (ours.copy_(torch.zeros(5, dtype=torch.uint8)) is None) and (theirs.copy_(torch.zeros(5, dtype=torch.uint8)) is None)
+    for t in (ours, theirs):                                             # a real .to() hands out a COPY of the patch list (ops.py:61)
+        moved = t.to(torch.int16)
+        moved.patches.append("x")
+        assert moved is not t and len(t.patches) == 1 and len(moved.patches) == 2
+    assert pkg.dequant.is_quantized(ours) and mods["dequant"].is_quantized(theirs)
+    # the call chains: with install() in front, our stand-in layers and the reference's layers run the same dequantizer on CPU
+    pkg.install.install(mods["dequant"], ro)
+    try:
+        monkeypatch.setattr(pkg.ops.GGMLLayer, "_dequantize", staticmethod(mods["dequant"].dequantize_tensor))
+        w = pkg.synth.make_tensor_bytes(Q.Q6_K, (8, 256), seed=4)
+        x = torch.randn(3, 256)
+        mine = pkg.ops.GGMLLinear(pkg.ops.GGMLTensor(torch.from_numpy(w.copy()), tensor_type=Q.Q6_K, tensor_shape=(8, 256)))
+        lin = ro.GGMLOps.Linear(256, 8)
+        lin.weight, lin.bias = torch.nn.Parameter(ro.GGMLTensor(torch.from_numpy(w.copy()), tensor_type=Q.Q6_K, tensor_shape=torch.Size((8, 256))), requires_grad=False), None
+        assert torch.equal(mine(x), lin(x))
+        ids = torch.tensor([[1, 7, 7, 0]])
+        emb_mine = pkg.ops.GGMLEmbedding(pkg.ops.GGMLTensor(torch.from_numpy(w.copy()), tensor_type=Q.Q6_K, tensor_shape=(8, 256)))
+        emb = ro.GGMLOps.Embedding(8, 256)
+        emb.weight = torch.nn.Parameter(ro.GGMLTensor(torch.from_numpy(w.copy()), tensor_type=Q.Q6_K, tensor_shape=torch.Size((8, 256))), requires_grad=False)
+        for out_dtype in (None, torch.float32, torch.bfloat16):
+            a, b = emb_mine(ids, out_dtype=out_dtype), emb(ids, out_dtype=out_dtype)
+            assert a.dtype == b.dtype and torch.equal(a, b), out_dtype
+    finally:
+        pkg.install.uninstall(mods["dequant"])
+
+
 def test_dense_cache_bookkeeping(pkg):
     """resident.DenseCache on CPU with a counting stand-in for the kernel call: hits, per-mode keys, invalidation by
     in-place writes and by the packed tensor's death, LRU eviction under the byte budget, the LoRA bypass."""
