@@ -19,8 +19,6 @@ What runs where
       re-implementation in this package; ``install()`` (install.py) wires this module in front of
       the reference's own functions, which keep handling those cases.
 """
-import ctypes
-
 import torch
 
 from . import _native

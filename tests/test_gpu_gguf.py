@@ -1,7 +1,5 @@
 """GGUF file -> HBM streaming and the device-resident state dict, on an MI355X: the uploaded arena is
 the file's data section byte for byte, and every tensor dequantized from it equals the oracle."""
-import os
-
 import numpy as np
 import pytest
 import torch

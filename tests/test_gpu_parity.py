@@ -3,7 +3,6 @@ Python interface, against (a) the committed golden vectors produced by the refer
 dequant.py, (b) the CPU oracle on seeded inputs at ragged / adversarial / full BASELINE sizes,
 (c) size-independent properties.  Tolerance: NONE -- every comparison is bit-exact (NaN payloads
 canonicalised); the 1-ULP allowance of the north star is unused slack."""
-import ctypes
 import hashlib
 import json
 import os
