@@ -63,15 +63,15 @@ template <class F> struct Tune : TuneSolo<F> {};
 #else
 template <class F> struct Tune : TuneCoop<F> {};
 #endif
-#define GGQ_TUNE(F, G_, COOP_, WAVES_, NTL_, XRUN_)                                              \
+#define GGQ_TUNE(F, G_, COOP_, WAVES_, XRUN_)                                                    \
     template <> struct Tune<F> {                                                                 \
         static constexpr int G = G_, WAVES = WAVES_;                                             \
-        static constexpr bool COOP = COOP_, NTL = NTL_, NTS = true;                              \
+        static constexpr bool COOP = COOP_, NTL = !PlainLoads<F>::V, NTS = true;                 \
         static constexpr uint32_t XRUN_LOG2 = XRUN_;                                             \
     }
-//       format      G   coop  waves  NT loads  log2(run)
-GGQ_TUNE(FmtQ3_K,    8,  false, 1,    false,    0);
-GGQ_TUNE(FmtQ6_K,    8,  false, 1,    false,    6);
+//       format      G   coop  waves  log2(run)
+GGQ_TUNE(FmtQ3_K,    8,  false, 1,    0);
+GGQ_TUNE(FmtQ6_K,    8,  false, 1,    6);
 #undef GGQ_TUNE
 
 // The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
