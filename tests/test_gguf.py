@@ -452,3 +452,62 @@ def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch)
 def sys_modules_reader(path):
     import sys
     return sys.modules["gguf"].GGUFReader(path)
+
+
+# ---------------------------------------------------------------- random containers (property test)
+
+def test_random_containers_round_trip(pkg, gf, tmp_path):
+    """Random metadata (every scalar type, strings with arbitrary unicode, arrays) and random tensor tables (types, ranks,
+    alignments, versions) written by the independent writer come back from the native parser value for value and byte for byte."""
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+    Q = pkg.qtypes.Q
+    ints = {UINT8: (0, 2 ** 8 - 1), INT8: (-2 ** 7, 2 ** 7 - 1), UINT16: (0, 2 ** 16 - 1), INT16: (-2 ** 15, 2 ** 15 - 1), UINT32: (0, 2 ** 32 - 1),
+            INT32: (-2 ** 31, 2 ** 31 - 1), UINT64: (0, 2 ** 64 - 1), INT64: (-2 ** 63, 2 ** 63 - 1)}
+    text = st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=40)
+
+    def scalar(t):
+        if t in ints:
+            return st.integers(*ints[t])
+        if t == FLOAT32:
+            return st.floats(width=32, allow_nan=False)
+        if t == FLOAT64:
+            return st.floats(allow_nan=False)
+        return st.booleans() if t == BOOL else text
+
+    scalar_types = list(ints) + [FLOAT32, FLOAT64, BOOL, STRING]
+    kv = st.one_of([st.tuples(st.just(t), scalar(t), st.none()) for t in scalar_types]
+                   + [st.tuples(st.just(ARRAY), st.lists(scalar(t), max_size=6), st.just(t)) for t in scalar_types])
+    qtypes = [Q.F32, Q.F16, Q.BF16, Q.Q4_0, Q.Q8_0, Q.Q4_K, Q.Q6_K, Q.IQ4_XS, Q.Q2_K]
+    tensor = st.tuples(st.sampled_from(qtypes), st.lists(st.integers(1, 3), min_size=0, max_size=3), st.integers(1, 3))
+
+    @hyp.settings(max_examples=60, deadline=None, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(kvs=st.lists(kv, max_size=8), tensors=st.lists(tensor, max_size=5), alignment=st.sampled_from([8, 16, 32, 64, 4096]),
+               version=st.sampled_from([2, 3]), seed=st.integers(0, 2 ** 16))
+    def check(kvs, tensors, alignment, version, seed):
+        w = GGUFWriter(arch="flux", alignment=alignment, version=version)
+        for i, (t, v, et) in enumerate(kvs):
+            w.add(f"k{i}.é", t, v, et)
+        rng, raw = np.random.default_rng(seed), []
+        for i, (q, outer, row_blocks) in enumerate(tensors):
+            bs, ts = pkg.qtypes.GGML_QUANT_SIZES[q]
+            dims = (row_blocks * bs,) + tuple(outer)                      # ggml order: the row (whole blocks) first
+            data = rng.integers(0, 256, int(np.prod(dims)) // bs * ts, dtype=np.uint8)
+            raw.append((f"t{i}.weight", q, dims, data))
+            w.add_tensor(f"t{i}.weight", q, dims, data)
+        path = w.write(str(tmp_path / "prop.gguf"))
+        with gf.GGUFFile(path) as f:
+            assert f.version == version and f.alignment == alignment and len(f.tensors) == len(raw)
+            for i, (t, v, et) in enumerate(kvs):
+                fld = f.get_field(f"k{i}.é")
+                assert fld.types == ([t] if t != ARRAY else [ARRAY, et])
+                got, want = (fld.value, tuple(v)) if t == ARRAY else ((fld.value,), (v,))
+                et = t if t != ARRAY else et
+                if et == FLOAT32:
+                    want = tuple(float(np.float32(x)) for x in want)
+                assert got == want and all(type(a) is type(b) for a, b in zip(got, want)), (t, et)
+            for info, (name, q, dims, data) in zip(f.tensors, raw):
+                assert (info.name, info.tensor_type, info.shape, info.nbytes) == (name, q, dims, data.size)
+                assert info.offset % alignment == 0 and np.array_equal(info.data.numpy(), data)
+
+    check()
