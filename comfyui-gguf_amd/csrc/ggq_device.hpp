@@ -589,8 +589,10 @@ GGQ_DEV void store_throttle()
 
 // SKEW: the tensor's base pointer itself may be only 2-byte aligned (a row inside a packed table): the misalignment of every
 // group start is then taken from the ADDRESS, not from the offset inside the tensor.
+// LPOL >= 0 (harness only): the group's bytes are fetched with BUFFER loads carrying that cache policy (aux bits: 1 = sc0, 2 = nt,
+// 16 = sc1) from a wave-uniform resource whose range ends at the tensor's last byte, instead of global loads with NTL.
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          bool SKEW = false>
+          bool SKEW = false, int LPOL = -1>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -635,6 +637,13 @@ struct Engine {
             if (left < (uint64_t)GROUP_BYTES) valid = a + (uint32_t)left;
         }
         u32x4 pf[NU];
+        if constexpr (LPOL >= 0) {
+            // raw buffer: units past the last one that holds valid bytes read as zero, so neither a bounds check nor a 64-bit address
+            // per lane (the range is rounded up to whole units: the same < 16-byte over-read inside an aligned unit as below)
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((valid + 15u) & ~15u), 0x00020000);
+#pragma unroll
+            for (int u = 0; u < NU; u++) pf[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((uint32_t)(lane + TEAM * u) * 16u), 0, LPOL);
+        } else
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const uint32_t o = (uint32_t)(lane + TEAM * u) * 16u;
@@ -749,11 +758,12 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total
 // of DEPENDENT scalar loads at the head of every wave: `coarse[c]` (optional) = the entry that holds group c << coarse_shift,
 // which leaves a 1-2 step forward scan instead of a log2(n)-step binary search -- a team holds its wave slots idle during
 // that chain, which costs the multi-wave (COOP) teams most (tests/microbench `ablocate`).
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
+          int LPOL = -1>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2,
                                                            const uint32_t* __restrict__ coarse, uint32_t coarse_shift)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0;                                // last entry with first_group <= g
         if (coarse != nullptr) {
             lo = coarse[g >> coarse_shift];

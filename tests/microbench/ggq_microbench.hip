@@ -1005,6 +1005,80 @@ static void ab_stream_all()
     ab_stream<ggq::FmtQ6_K, 8, false, false>("Q6_K", 9, 64);
 }
 
+// ---- load cache policy: buffer loads with sc0 / sc1 / nt against the shipped global loads ---------------------------
+template <class F, int G, int WAVES, bool COOP, int LPOL>
+static bool check_lpol()
+{
+    const QT* q = nullptr;
+    for (const QT& x : QTS) if (x.id == F::ID) q = &x;
+    bool ok = true;
+    for (uint64_t n : {(uint64_t)1, (uint64_t)(G - 1), (uint64_t)G, (uint64_t)(3 * G + 1), (uint64_t)(F::BS == 32 ? 20011 : 2503)}) {
+        std::vector<uint8_t> packed; make_blocks(*q, n, (int)(n & 1), packed);
+        std::vector<uint16_t> want(n * F::BS), got(n * F::BS);
+        ggq_oracle_dequant_f16(F::ID, packed.data(), n, want.data());
+        uint8_t *dp, *dout;
+        HIP_CHECK(hipMalloc(&dp, packed.size())); HIP_CHECK(hipMalloc(&dout, n * F::BS * 2 + 256));
+        HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
+        const uint64_t groups = (n + G - 1) / G;
+        const ggq::Desc tab[1] = {{dp, dout, n, 0}};
+        ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, sizeof tab)); HIP_CHECK(hipMemcpy(dt, tab, sizeof tab, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+                           dt, 1u, groups, 0u, nullptr, 0u);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
+        uint8_t guard[256]; HIP_CHECK(hipMemcpy(guard, dout + n * F::BS * 2, 256, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n * F::BS; i++) ok &= canon16(got[i]) == canon16(want[i]);
+        for (int g = 0; g < 256; g++) ok &= guard[g] == 0xCD;
+        HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(dout)); HIP_CHECK(hipFree(dt));
+    }
+    return ok;
+}
+
+template <class F, int G, int WAVES, bool COOP, int LPOL>
+static void ab_add_lpol(AB& ab, const char* name, Pool& P, uint32_t xrun)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    ab.to_free.push_back(dt);
+    const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s %s G=%d buffer loads%s%s%s xrun=%u", name, COOP ? "coop" : "solo", G, (LPOL & 1) ? " sc0" : "", (LPOL & 16) ? " sc1" : "", (LPOL & 2) ? " nt" : "", xrun);
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3(blocks), dim3(WAVES * 64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_lpol<F, G, WAVES, COOP, LPOL>()});
+}
+
+template <class F, int G, bool NTL, bool COOP>
+static void ab_load_policy(const char* name, int qi, uint32_t xr)
+{
+    Pool P = make_pool(QTS[qi], 64);
+    printf("POOL %s pairs=64\n", name);
+    AB ab;
+    constexpr int W = COOP ? 4 : 1;
+    if (COOP) ab_add<F, G, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, xr);                  // shipped: global loads
+    else ab_add<F, G, NTL, true, 1, 0, false, -1>(ab, name, P, F::ID == 14 ? 4096 : 0, xr);
+    ab_add_lpol<F, G, W, COOP, 0>(ab, name, P, xr);
+    ab_add_lpol<F, G, W, COOP, 2>(ab, name, P, xr);
+    ab_add_lpol<F, G, W, COOP, 1>(ab, name, P, xr);
+    ab_add_lpol<F, G, W, COOP, 16>(ab, name, P, xr);
+    ab_add_lpol<F, G, W, COOP, 17>(ab, name, P, xr);
+    ab_add_lpol<F, G, W, COOP, 18>(ab, name, P, xr);
+    ab.run(9, 3);
+    free_pool(P);
+}
+
+static void ab_load_policy_all()
+{
+    ab_load_policy<ggq::FmtQ4_K, 16, true, true>("Q4_K", 7, 5);
+    ab_load_policy<ggq::FmtQ2_K, 16, false, true>("Q2_K", 5, 5);
+    ab_load_policy<ggq::FmtQ3_K, 8, false, false>("Q3_K", 6, 0);
+    ab_load_policy<ggq::FmtQ6_K, 8, false, false>("Q6_K", 9, 6);
+    ab_load_policy<ggq::FmtQ8_0, 128, true, true>("Q8_0", 4, 5);
+}
+
 int main(int argc, char** argv)
 {
     const std::string what = argc > 1 ? argv[1] : "all";
@@ -1029,5 +1103,6 @@ int main(int argc, char** argv)
     if (what == "fillrows") fill_rows();
     if (what == "fillpol") fill_policy();
     if (what == "abstream") ab_stream_all();
+    if (what == "abload") ab_load_policy_all();
     return rc ? 1 : 0;
 }
