@@ -440,3 +440,19 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
     finally:
         pkg.install.uninstall(rd)
     assert ro.GGMLOps.Embedding.forward_ggml_cast_weights is ref_emb_forward
+
+
+def test_tools_and_entry_points_at_least_parse():
+    """Every script under tools/ (they need a GPU to RUN) byte-compiles, and the argparse-driven ones answer --help."""
+    import py_compile
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(f for f in os.listdir(os.path.join(root, "tools")) if f.endswith(".py"))
+    assert len(scripts) >= 8
+    for f in scripts + ["../bench.py", "../__graft_entry__.py"]:
+        py_compile.compile(os.path.join(root, "tools", f), doraise=True)
+    for f in ("flux_forward_emulation.py", "mode_table.py", "build_variant.py", "upload_sweep.py"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", f), "--help"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "usage" in r.stdout.lower(), (f, r.stderr[-500:])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout
