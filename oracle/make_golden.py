@@ -49,11 +49,12 @@ class _FakeGGML:
         self.device = data.device
 
 
-def main():
+def main(out_dir=GOLDEN, large=True):
+    """``large=False`` skips the hashes of the big inputs (tests regenerate the small fixtures to check the committed ones)."""
     pkg = load_package()
     qt, synth = pkg.qtypes, pkg.synth
     ref = reference.load_reference_dequant()
-    os.makedirs(GOLDEN, exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(0)
 
     for q in qt.HIP_QTYPES:
@@ -71,7 +72,7 @@ def main():
         tbf = ref.dequantize_tensor(_FakeGGML(sdata, q, torch.Size((len(sub), bs))), dtype=torch.bfloat16)
         assert o32.dtype == torch.float32 and obf.dtype == torch.bfloat16 and tbf.dtype == torch.bfloat16
         np.savez_compressed(
-            os.path.join(GOLDEN, f"{q.name}.npz"),
+            os.path.join(out_dir, f"{q.name}.npz"),
             blocks=blocks,
             out_f16=out.view(torch.int16).numpy().view(np.uint16),
             sub=sub,
@@ -84,8 +85,10 @@ def main():
     raw = np.random.default_rng(77).integers(0, 256, size=2 * 4096, dtype=np.uint8)
     o = ref.dequantize(torch.from_numpy(raw.copy()), qt.Q.BF16, (4096,))
     assert o.dtype == torch.float32
-    np.savez_compressed(os.path.join(GOLDEN, "BF16.npz"), blocks=raw, out_f32=o.view(torch.int32).numpy().view(np.uint32))
+    np.savez_compressed(os.path.join(out_dir, "BF16.npz"), blocks=raw, out_f32=o.view(torch.int32).numpy().view(np.uint32))
 
+    if not large:
+        return
     hashes = {}
     large = LARGE + [(q.name, (3072, 3072), 1 if q in qt.LEGACY_QTYPES else 2) for q in qt.HIP_QTYPES]
     for name, shape, seed in large:
@@ -100,7 +103,7 @@ def main():
             "n_elements": int(np.prod(shape)),
         }
         print(key, hashes[key]["out_f16_sha256"][:16])
-    with open(os.path.join(GOLDEN, "large_hashes.json"), "w") as f:
+    with open(os.path.join(out_dir, "large_hashes.json"), "w") as f:
         json.dump(hashes, f, indent=1, sort_keys=True)
 
 

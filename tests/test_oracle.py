@@ -146,3 +146,22 @@ def test_simd_throughput_leg_equals_the_soft_float_checker(pkg, golden_dir, mode
     assert oracle.dequant_f16(pkg.qtypes.Q.Q4_K, np.zeros(0, np.uint8), simd=True).size == 0
     with pytest.raises(ValueError):
         oracle.dequant_f16(99, np.zeros(144, np.uint8), simd=True)
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_committed_fixtures_are_what_the_generator_writes(golden_dir, tmp_path, capsys):
+    """tests/golden/*.npz regenerated by oracle/make_golden.py (the reference's own dequant.py, verbatim) into a scratch
+    directory: every array of every fixture identical to the committed one -- the fixtures are the script's output, nothing else."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ggq_make_golden", os.path.join(os.path.dirname(os.path.abspath(oracle.__file__)), "make_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.main(out_dir=str(tmp_path), large=False)
+    capsys.readouterr()
+    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 13
+    for f in names:
+        a, b = np.load(os.path.join(golden_dir, f)), np.load(os.path.join(tmp_path, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (f, k)
