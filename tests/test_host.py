@@ -456,3 +456,21 @@ def test_tools_and_entry_points_at_least_parse():
         assert r.returncode == 0 and "usage" in r.stdout.lower(), (f, r.stderr[-500:])
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "--gpus" in r.stdout
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_dispatch_tables_equal_the_reference_live(pkg):
+    """The format table and the predicates around it against the reference's dequant.py executed verbatim: the HIP path serves
+    exactly the formats the reference has block functions for (nothing falls back to gguf's numpy path that did not before)."""
+    ref = reference.load_reference_dequant()
+    dq, Q = pkg.dequant, pkg.qtypes.Q
+    assert {int(k) for k in dq.dequantize_functions} == {int(k) for k in ref.dequantize_functions}
+    assert {int(k) for k in dq.TORCH_COMPATIBLE_QTYPES if k is not None} == {int(k) for k in ref.TORCH_COMPATIBLE_QTYPES if k is not None}
+    assert (None in dq.TORCH_COMPATIBLE_QTYPES) == (None in ref.TORCH_COMPATIBLE_QTYPES)
+    probes = [None, torch.zeros(3), _Carrier(torch.zeros(4, 4).half(), Q.F16, torch.Size((4, 4))), _Carrier(torch.zeros(4), Q.F32, torch.Size((4,))),
+              _Carrier(torch.zeros(8, dtype=torch.uint8), Q.BF16, torch.Size((4,))), _Carrier(torch.zeros(144, dtype=torch.uint8), Q.Q4_K, torch.Size((256,))),
+              _Carrier(torch.zeros(66, dtype=torch.uint8), Q.IQ2_XXS, torch.Size((256,)))]
+    for t in probes:
+        assert dq.is_quantized(t) == ref.is_quantized(t) and dq.is_torch_compatible(t) == ref.is_torch_compatible(t), getattr(t, "tensor_type", t)
+    for q in pkg.qtypes.HIP_QTYPES:
+        assert tuple(pkg.qtypes.GGML_QUANT_SIZES[q]) == tuple(sys.modules["gguf"].GGML_QUANT_SIZES[q])
