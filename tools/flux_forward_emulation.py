@@ -3,11 +3,12 @@
 run the way GGMLOps.Linear.forward does (reference ops.py:242-244) -- dequantize the weight, F.linear, drop it -- for one
 denoising step's worth of tokens, against the same F.linear calls on weights dequantized once up front.
 
-    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5]
+    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5] [--dense-cache-gb N] [--fused-small-m]
 
 Prints one JSON line: ms per emulated step with on-the-fly dequant, with resident dense weights, and the difference
 (the cost of the dequant path per step).  Layers run back to back on one stream; img/txt token counts are not modelled
-separately (every layer sees --tokens rows), modulation layers see 1 row (they act on the conditioning vector)."""
+separately (every layer sees --tokens rows), modulation layers see 1 row (they act on the conditioning vector).
+--dense-cache-gb / --fused-small-m switch on the two opt-ins of install() for the quantized pass (resident.DenseCache, fused.linear_small)."""
 import argparse
 import json
 import os
