@@ -372,14 +372,13 @@ def _same_state_dict(ours, theirs):
         assert bool(getattr(a, "is_largest_weight", False)) == bool(getattr(b, "is_largest_weight", False)), key
 
 
-@pytest.mark.filterwarnings("ignore::DeprecationWarning")          # the reference's int(np.array([x])) under numpy 2
-@pytest.mark.skipif(not os.path.isfile("/root/reference/loader.py"), reason="/root/reference not present (GPU box)")
-def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch):
-    """gguf_sd_loader / get_field / get_list_field / get_orig_shape against the reference's own functions executed verbatim on
-    the same files: same state dicts (keys and their order, types, logical shapes, dtypes, bytes, largest-weight mark),
-    same architecture, same exception types and messages."""
-    Q, ours = pkg.qtypes.Q, pkg.loader
-    ref = _reference_loader(pkg, monkeypatch)
+LOADER_CALLS = [dict(), dict(return_arch=True), dict(handle_prefix=None), dict(handle_prefix="other."), dict(is_text_model=True, return_arch=True),
+                dict(handle_prefix="", return_arch=True)]
+
+
+def _loader_case_files(pkg, tmp_path):
+    """The files the loader is compared on (deterministic: same bytes wherever they are built)."""
+    Q = pkg.qtypes.Q
     pre = "model.diffusion_model."
     files = {
         "flux": _model_file(pkg, tmp_path, extra_kv=[(f"comfy.gguf.orig_shape.{pre}x.conv.weight", ARRAY, [2, 3, 32], INT32),
@@ -414,11 +413,23 @@ def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch)
             data = np.arange(n, dtype=np.float32) if q == Q.F32 else np.arange(n, dtype=np.float16) if q == Q.F16 else pkg.synth.make_tensor_bytes(q, shape, seed=90 + i)
             w.add_tensor(name, q, tuple(reversed(shape)), data)
         files[label] = w.write(str(tmp_path / f"{label}.gguf"))
+    return files
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")          # the reference's int(np.array([x])) under numpy 2
+@pytest.mark.skipif(not os.path.isfile("/root/reference/loader.py"), reason="/root/reference not present (GPU box)")
+def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch):
+    """gguf_sd_loader / get_field / get_list_field / get_orig_shape against the reference's own functions executed verbatim on
+    the same files: same state dicts (keys and their order, types, logical shapes, dtypes, bytes, largest-weight mark),
+    same architecture, same exception types and messages."""
+    ours = pkg.loader
+    ref = _reference_loader(pkg, monkeypatch)
+    pre = "model.diffusion_model."
+    files = _loader_case_files(pkg, tmp_path)
     import importlib
     detector = importlib.import_module("refldr.tools.convert").detect_arch
 
-    calls = [dict(), dict(return_arch=True), dict(handle_prefix=None), dict(handle_prefix="other."), dict(is_text_model=True, return_arch=True),
-             dict(handle_prefix="", return_arch=True)]
+    calls = LOADER_CALLS
     compared = 0
     for label, path in files.items():
         for kw in calls:
@@ -511,3 +522,61 @@ def test_random_containers_round_trip(pkg, gf, tmp_path):
                 assert info.offset % alignment == 0 and np.array_equal(info.data.numpy(), data)
 
     check()
+
+
+# ---------------------------------------------------------------- the same comparison against COMMITTED reference outcomes
+
+def _stand_in_detector(keys):
+    """Architecture of a file without metadata, for the two shapes the case files use (the reference's own detector,
+    tools/convert.py, produced the committed expectations; it does not travel to the GPU box)."""
+    class _A:
+        arch = "flux" if "double_blocks.0.img_attn.proj.weight" in keys else "sdxl" if "label_emb.0.0.weight" in keys else None
+    if _A.arch is None:
+        raise AssertionError("Unknown model architecture!")
+    return _A()
+
+
+def _loader_outcome(fn, path, tmp_path, **kw):
+    """JSON-able summary of one gguf_sd_loader call: the state dict entry by entry (bytes by sha256), the architecture, or the error."""
+    import hashlib
+    try:
+        res = fn(path, **kw)
+    except Exception as e:                                     # noqa: BLE001
+        return {"error": type(e).__name__, "message": str(e).split(", got ")[0].replace(str(tmp_path), "<dir>")}
+    sd, arch = res if kw.get("return_arch") else (res, None)
+    entries = []
+    for key, t in sd.items():
+        tt = getattr(t, "tensor_type", None)
+        raw = t.as_subclass(torch.Tensor).contiguous().reshape(-1).view(torch.uint8).numpy().tobytes()
+        entries.append([key, None if tt is None else int(tt), [int(d) for d in t.shape], str(t.dtype), [int(d) for d in t.size()],
+                        hashlib.sha256(raw).hexdigest()[:16], bool(getattr(t, "is_largest_weight", False))])
+    return {"arch": arch, "entries": entries}
+
+
+def write_loader_golden(pkg, out_path, tmp_path):
+    """tests/golden/loader_cases.json: the REFERENCE loader's outcome (loader.py executed verbatim, _reference_loader) for every
+    case file x call.  Run by tests/make_loader_golden.py in the build container."""
+    import json
+    from _pytest.monkeypatch import MonkeyPatch
+    with MonkeyPatch.context() as mp:
+        ref = _reference_loader(pkg, mp)
+        files = _loader_case_files(pkg, tmp_path)
+        cases = {label: [_loader_outcome(ref.gguf_sd_loader, path, tmp_path, **kw) for kw in LOADER_CALLS] for label, path in files.items()}
+    with open(out_path, "w") as f:
+        json.dump({"calls": [{k: v for k, v in kw.items()} for kw in LOADER_CALLS], "cases": cases}, f, indent=1, sort_keys=True)
+    return cases
+
+
+def test_loader_matches_the_committed_reference_outcomes(pkg, tmp_path, golden_dir):
+    """Everywhere (GPU box included): the case files are rebuilt byte for byte and gguf_sd_loader must give what the reference's
+    loader gave for them when tests/golden/loader_cases.json was generated."""
+    import json
+    with open(os.path.join(golden_dir, "loader_cases.json")) as f:
+        golden = json.load(f)
+    assert golden["calls"] == [dict(kw) for kw in LOADER_CALLS]
+    files = _loader_case_files(pkg, tmp_path)
+    assert sorted(files) == sorted(golden["cases"])
+    for label, path in files.items():
+        for kw, want in zip(LOADER_CALLS, golden["cases"][label]):
+            got = _loader_outcome(pkg.loader.gguf_sd_loader, path, tmp_path, detect_arch=_stand_in_detector, **kw)
+            assert got == want, (label, kw)
