@@ -40,7 +40,7 @@ def main(root):
     print("# correction: read bytes = FETCH_SIZE * 2048 (gfx950 counts 16 B/lane streams at half rate; calibrated below on 1 GiB copies), write bytes = WRITE_SIZE * 1024")
     print(f"{'kernel (compute->out)':28s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s} {'read B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'write B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'avg us':>9s}")
     for k in fetch:
-        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, \w+)?>", k)
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, -?\w+)*>", k)
         if m:
             fmt, out, comp = m.groups()
             name = f"{fmt} {DT[comp]}->{DT[out]}"
@@ -65,7 +65,7 @@ def main(root):
     print("\n# SQ pass (per launch; SQ_* cycle counters are quad-cycles summed over waves)")
     print(f"{'kernel (compute->out)':28s} " + " ".join(f"{n:>22s}" for n in names))
     for k in cols["SQ_WAVES"]:
-        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, \w+)?>", k)
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, -?\w+)*>", k)
         if not m:
             continue
         fmt, out, comp = m.groups()
