@@ -125,14 +125,59 @@ def per_launch_stats(plan, reps, device):
     return ms[len(ms) // 2], ms[0]
 
 
-def cpu_baseline(pkg, plan, qtype, budget_s):
-    """The CPU leg, timed on this box's host cores on a bounded sample of the same workload: the first
-    tensors of the pool (same packed bytes, copied back from the GPU), repeated for ~budget_s seconds.
-    kind 'port': the reference is Python/torch and cannot travel to the GPU box, so the timed code is the
-    oracle's throughput leg (oracle/ggq_oracle_simd.c: the same op sequence with AVX2+F16C and OpenMP --
-    ~6x faster than the reference's own torch-CPU path on the build container, oracle/time_reference_cpu.py);
-    hosts without AVX2/F16C time the soft-float checker instead.  Also re-checks parity: the GPU output
-    of the sample must equal the soft-float oracle's bit for bit."""
+def _median_min(fn, budget_s, min_reps, warmup):
+    for _ in range(warmup):
+        fn()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < min_reps or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], times[0], len(times)
+
+
+def cpu_baseline_reference(pkg, plan, qtypes, budget_s):
+    """kind 'reference': the reference's OWN torch-CPU path -- ``dequantize(data, qtype, oshape)`` of its dequant.py
+    (dequant.py:30-44), executed verbatim (oracle/reference.py: /root/reference, or the copy oracle/stage_reference.py staged
+    into oracle/_ref for the GPU box) -- timed on THIS box's host cores, in this process, on the same packed bytes the GPU just
+    dequantized: the first (3072x3072, 3072x12288) pair of the pool (or the first tensors of a mixed set), copied back from
+    HBM.  >= 3 warm-up and >= 10 timed passes, median and min; torch's intra-op thread count and the visible CPU count are
+    stated.  Also the strongest parity statement the run can make: the reference's output == the GPU's output, bit for bit."""
+    import numpy as np
+    from oracle import reference
+    if not reference.available():
+        return None
+    ref = reference.load_reference_dequant()
+    n_sample = min(2, len(plan.outputs))
+    packed = [plan._keep[i].cpu() for i in range(n_sample)]
+    shapes = [tuple(plan.outputs[i].shape) for i in range(n_sample)]
+    qs = [qtypes[i] for i in range(n_sample)]
+    nbytes = sum(pkg.qtypes.algorithmic_bytes(q, int(np.prod(sh))) for q, sh in zip(qs, shapes))
+    parity = True
+    for i in range(n_sample):
+        want = ref.dequantize(packed[i], qs[i], shapes[i])
+        parity = parity and want.dtype == torch.float16 and bool(torch.equal(want.view(torch.int16), plan.outputs[i].cpu().view(torch.int16)))
+
+    def one_pass():
+        for p, q, sh in zip(packed, qs, shapes):
+            ref.dequantize(p, q, sh)
+
+    med, tmin, reps = _median_min(one_pass, budget_s, 10, 3)
+    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "reference",
+            "sample": (f"reference dequant.py:30 dequantize() verbatim ({reference.source()} copy) on torch-CPU, {torch.get_num_threads()} intra-op threads, "
+                       f"{os.cpu_count()} host CPUs visible; {' + '.join(f'{q.name} {sh[0]}x{sh[1]}' for q, sh in zip(qs, shapes))} "
+                       f"(same packed bytes the GPU read), {reps} passes after 3 warm-up, median; (in+out) bytes / time"),
+            "min_GBps": round(nbytes / tmin / 1e9, 3), "median_ms": round(med * 1e3, 2), "min_ms": round(tmin * 1e3, 2),
+            "parity_vs_gpu": "bit-exact" if parity else "MISMATCH"}
+
+
+def cpu_baseline_port(pkg, plan, qtype, budget_s):
+    """kind 'port': the oracle's throughput leg (oracle/ggq_oracle_simd.c: the same op sequence with AVX2+F16C and OpenMP) on the
+    first tensors of the pool -- the fastest CPU implementation of this path the repo has, reported BESIDE the reference's own
+    torch-CPU figure so that the GPU/CPU ratio is not flattered by a slow baseline; hosts without AVX2/F16C time the soft-float
+    checker instead.  Also re-checks parity: the GPU output of the sample must equal the soft-float oracle's bit for bit."""
     import numpy as np
     import oracle
     n_sample = min(8, len(plan.outputs))                       # 8 tensors = 4 (B + C) pairs, 189 M elements: out of any CPU cache
@@ -153,20 +198,12 @@ def cpu_baseline(pkg, plan, qtype, budget_s):
 
     # OpenMP on every hardware thread of a shared box is not always the fastest setting: try a few team
     # sizes, report the best median and ITS thread count.
-    counts = sorted({c for c in (1, 8, 16, 32, 64, 128, max_threads) if c <= max_threads})
+    counts = sorted({c for c in (1, 16, 64, 128, max_threads) if c <= max_threads})
     best = None
     for c in counts:
-        one_pass(c)                                            # warm-up: page in the outputs, spin up the team
-        times = []
-        t_end = time.perf_counter() + budget_s / len(counts)
-        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 200):
-            t0 = time.perf_counter()
-            one_pass(c)
-            times.append(time.perf_counter() - t0)
-        times.sort()
-        med = times[len(times) // 2]
+        med, tmin, reps = _median_min(lambda: one_pass(c), budget_s / len(counts), 3, 1)
         if best is None or med < best[0]:
-            best = (med, c, len(times), times[0])
+            best = (med, c, reps, tmin)
     med, threads, reps, tmin = best
     leg = "oracle/ggq_oracle_simd.c (AVX2+F16C)" if simd else "oracle/ggq_oracle.c (soft-float; host lacks AVX2/F16C)"
     return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
@@ -176,24 +213,35 @@ def cpu_baseline(pkg, plan, qtype, budget_s):
             "parity_vs_gpu": "bit-exact" if parity else "MISMATCH"}
 
 
-def run_flux(pkg, args, rank, world, device, fence):
-    """configs[3]: full FLUX.1-dev weight set, mixed quant types, resident in HBM, sharded over ranks."""
-    if args.workload == "sd35-t5":
+def cpu_baselines(pkg, plan, qtypes, budget_s):
+    """(cpu_baseline, cpu_baseline_port): the reference's own torch-CPU path when its sources are present (north_star: "the
+    reference's CPU torch path timed on the same box's host cores in the same run"), the AVX2 port beside it.  Without the
+    reference (neither /root/reference nor a staged oracle/_ref) the port IS the baseline, labelled as such."""
+    ref = cpu_baseline_reference(pkg, plan, qtypes, budget_s * 0.5)
+    port = cpu_baseline_port(pkg, plan, qtypes[0], budget_s * 0.5) if len(set(qtypes[:8])) == 1 else None
+    return (ref, port) if ref is not None else (port, None)
+
+
+def run_flux(pkg, args, rank, world, device, fence, workload=None, cpu_seconds=None):
+    """configs[3] / configs[4]: a full weight set, mixed quant types, resident in HBM, sharded over ranks."""
+    workload = workload or args.workload
+    cpu_seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
+    if workload == "sd35-t5":
         manifest, label = pkg.manifests.sd35_t5(args.mix), "BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors"
     else:
         manifest, label = pkg.manifests.flux_dev(args.mix), "BASELINE configs[3]: full FLUX.1-dev weight set"
     mine = pkg.sharding.shard(manifest, rank, world)
     plan = build_pool(pkg, mine, device, seed0=7000 + 1000 * rank)
-    gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup, device, fence)
-    ms_per_step = max_over_ranks(gpu_ms / args.steps, device)
+    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, device, fence, args.regions)
     total_bytes = sum(pkg.sharding.tensor_cost(e) for e in manifest)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
     result = None
     if rank == 0:
-        achieved = plan.bytes / (gpu_ms / args.steps * 1e-3) / 1e9
+        achieved = plan.bytes / (gpu_ms_step * 1e-3) / 1e9
         qcount = {}
         for _, q, _ in manifest:
             qcount[q.name] = qcount.get(q.name, 0) + 1
+        traffic, traffic_source = load_traffic(pkg, f"{workload}:{args.mix}") if world == 1 else (None, "PMC figures are per single-GPU launch")
         result = {
             "metric": "dequant GB/s (packed in -> fp16 out), (in+out) bytes / time",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,14 +251,19 @@ def run_flux(pkg, args, rank, world, device, fence):
                                    f"HBM-resident, tensor list sharded over {world} GPU(s)",
                        "elements": sum(s[0] * s[1] for _, _, s in manifest), "bytes_per_step": total_bytes,
                        "kernels_per_step_rank0": plan.kernels, "imbalance": round(pkg.sharding.imbalance(manifest, world), 4),
-                       "parallelism": f"tensor-list sharding x{world}, no collectives"},
+                       "parallelism": f"tensor-list sharding x{world}, no collectives",
+                       "timed_regions_ms_per_step": regions, "reported": "median region"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "ggq::dequant_many<Fmt*, ...> (one launch per format present)",
-                         "algorithmic_bytes_per_launch": plan.bytes, "avg_launch_ms": round(gpu_ms / args.steps, 5),
-                         "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
+                         "algorithmic_bytes_per_launch": plan.bytes, "avg_launch_ms": round(gpu_ms_step, 5),
+                         "host_wall_ms_per_step": round(wall_ms_step, 5)},
             "cpu_baseline": None,
         }
+        if world == 1 and cpu_seconds > 0:
+            result["cpu_baseline"], port = cpu_baselines(pkg, plan, [q for _, q, _ in mine], cpu_seconds)
+            if port is not None:
+                result["cpu_baseline_port"] = port
     plan.close()
     return result
 
@@ -293,15 +346,37 @@ def run_flux_gguf(pkg, args, device):
     return result
 
 
-def load_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC summary (collected in separate rocprofv3 --pmc
-    passes and corrected per MI355X_MICROARCH.md; see profiles/README.md), or None."""
+def load_traffic(pkg, workload_key):
+    """(HBM bytes per launch, source) from the committed PMC summary -- collected in separate rocprofv3 --pmc passes and corrected
+    per MI355X_MICROARCH.md (profiles/README.md).  The figure is only reported when the library THIS run loaded was compiled from
+    the very sources the counters were collected on (``ggq_build_id()`` == the id recorded in profiles/pmc_traffic.json); after
+    any kernel change it is null until the counters are re-collected, and ``traffic_source`` says why."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    build_id = pkg._native.lib().ggq_build_id().decode()
     try:
         with open(path) as f:
-            return json.load(f).get(workload_key)
+            table = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, f"no profiles/pmc_traffic.json (library build {build_id})"
+    pmc_id = table.get("_build_id")
+    if pmc_id != build_id:
+        return None, f"stale: PMC counters were collected on library build {pmc_id}, this run loaded build {build_id} -- re-collect (tools/pmc_summarize.py)"
+    if workload_key not in table:
+        return None, f"no PMC entry for {workload_key!r} (library build {build_id})"
+    return table[workload_key], f"{table.get('_provenance', 'profiles/pmc_traffic.json')}; library build {build_id}"
+
+
+def median_region(pkg, plan, args, device, fence, regions):
+    """`regions` timed regions of exactly K launches each (the first after W warm-up launches), every one bracketed by the
+    fence on both sides and reduced with MAX over ranks; the reported step time is the MEDIAN region's.  Returns
+    (ms_per_step of the median region [MAX over ranks], this rank's gpu ms per step in that region, wall ms per step, all regions)."""
+    rows = []
+    for r in range(regions):
+        gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup if r == 0 else 0, device, fence)
+        rows.append((max_over_ranks(gpu_ms / args.steps, device), gpu_ms / args.steps, wall_ms / args.steps))
+    order = sorted(range(regions), key=lambda k: rows[k][0])
+    med = rows[order[regions // 2]]
+    return med[0], med[1], med[2], [round(r[0], 5) for r in rows]
 
 
 def main():
@@ -313,7 +388,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=64, help="(3072x3072 + 3072x12288) pairs in the per-GPU pool")
     ap.add_argument("--no-per-qtype", action="store_true", help="skip the per-format table")
     ap.add_argument("--no-per-mode", action="store_true", help="skip the (dequant_dtype, dtype) table of the headline format")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline legs (0 = skip)")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of K steps each; the median region is reported")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the configs[3] / configs[4] sub-lines of the default run")
     ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
@@ -381,17 +458,16 @@ def main():
     bytes_rank = plan.bytes
     assert plan.kernels == 1
 
-    gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup, device, fence)
-    ms_per_step = max_over_ranks(gpu_ms / args.steps, device)
+    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, device, fence, args.regions)
     total_bytes = bytes_rank * world                                       # identical pools on every rank
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
 
     result = None
     if rank == 0:
-        achieved = bytes_rank / (gpu_ms / args.steps * 1e-3) / 1e9        # rank 0's own kernel
+        achieved = bytes_rank / (gpu_ms_step * 1e-3) / 1e9                # rank 0's own kernel, median region
         n_el = sum(s[0] * s[1] for _, _, s in mine)
         wl = f"BASELINE configs[2] {head_q.name}: FLUX.1-dev linear shapes, {args.pairs} x (3072x3072 + 3072x12288) per GPU"
-        traffic = load_traffic(f"{head_q.name}:pairs{args.pairs}")
+        traffic, traffic_source = load_traffic(pkg, f"{head_q.name}:pairs{args.pairs}")
         med_ms, min_ms = per_launch_stats(plan, max(20, args.steps), device)
         in_bytes = sum(t.numel() for t in plan._keep)
         result = {
@@ -402,15 +478,17 @@ def main():
             "config": {"workload": wl, "qtype": head_q.name, "elements_per_gpu": n_el, "bytes_per_step_per_gpu": bytes_rank,
                        "tensors_per_gpu": len(mine), "parallelism": f"tensor-list sharding x{world}, no collectives",
                        "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2),
+                       "timed_regions_ms_per_step": regions, "reported": f"median of {len(regions)} timed regions of {args.steps} steps",
+                       "library_build": pkg._native.lib().ggq_build_id().decode(),
                        # the three rates of SURVEY.md section 8d, per GPU (rank 0): packed in / dense out / both, over the same time
-                       "rates_GBps": {"in": round(in_bytes / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
-                                      "out": round((bytes_rank - in_bytes) / (gpu_ms / args.steps * 1e-3) / 1e9, 1),
+                       "rates_GBps": {"in": round(in_bytes / (gpu_ms_step * 1e-3) / 1e9, 1),
+                                      "out": round((bytes_rank - in_bytes) / (gpu_ms_step * 1e-3) / 1e9, 1),
                                       "in_plus_out": round(achieved, 1)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"ggq::dequant_many<Fmt{head_q.name}, ...>", "algorithmic_bytes_per_launch": bytes_rank,
-                         "avg_launch_ms": round(gpu_ms / args.steps, 5), "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
-                         "host_wall_ms_per_step": round(wall_ms / args.steps, 5)},
+                         "avg_launch_ms": round(gpu_ms_step, 5), "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
+                         "host_wall_ms_per_step": round(wall_ms_step, 5)},
         }
     plan_head = plan
 
@@ -451,12 +529,25 @@ def main():
         result["per_mode"] = per_mode
 
     if rank == 0:
+        result["cpu_baseline"] = None
         if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"] = cpu_baseline(pkg, plan_head, head_q, args.cpu_seconds)
-        else:
-            result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+            result["cpu_baseline"], port = cpu_baselines(pkg, plan_head, [head_q] * len(plan_head.outputs), args.cpu_seconds)
+            if port is not None:
+                result["cpu_baseline_port"] = port
     plan_head.close()
+    del plan_head, plan
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_workloads:
+            # BASELINE configs[3] and configs[4] measured in the SAME run (each is also a workload of its own: --workload flux /
+            # sd35-t5): the full weight sets, one mixed-format plan launch per step, with their own roofline and CPU legs
+            subs = {}
+            for wl_name in ("flux", "sd35-t5"):
+                sub = run_flux(pkg, args, 0, 1, device, lambda: torch.cuda.synchronize(device), workload=wl_name, cpu_seconds=min(args.cpu_seconds, 6.0))
+                subs[wl_name] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline")}
+                torch.cuda.empty_cache()
+            result["workloads"] = subs
+        print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

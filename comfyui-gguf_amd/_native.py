@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -66,6 +66,7 @@ SYMBOLS = {
     "ggq_strerror": (ctypes.c_char_p, [_int]),
     "ggq_last_hip_error": (_int, []),
     "ggq_abi_version": (_int, []),
+    "ggq_build_id": (ctypes.c_char_p, []),
     "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
     "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),
@@ -95,6 +96,17 @@ class GGQNativeError(RuntimeError):
     """libggq_hip.so is missing / unloadable / returned a failing status."""
 
 
+def source_id():
+    """First 16 hex digits of the sha256 over the compiler flags and every source / header of the library: what
+    ``ggq_build_id()`` of an in-tree build returns (stamped with -DGGQ_BUILD_ID at compile time)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for p in SOURCES + HEADERS:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc_path():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
@@ -122,7 +134,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="ggq_build_") as tmp:
         out = os.path.join(tmp, "libggq_hip.so")
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-save-temps=obj", "-o", out] + SOURCES
+        cmd = [hipcc_path()] + HIPCC_FLAGS + [f'-DGGQ_BUILD_ID="{source_id()}"', "-save-temps=obj", "-o", out] + SOURCES
         proc = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         if verbose or proc.returncode:
             print(" ".join(cmd))

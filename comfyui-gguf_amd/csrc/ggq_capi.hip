@@ -174,7 +174,7 @@ hipError_t launch_one(const Desc& d, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
     return hipGetLastError();
 }
 
@@ -208,7 +208,7 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, 0, false, -1, 1, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_of<T, F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
+    hipLaunchKernelGGL((dequant_many<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, table, n, groups, xrun_of<T, F>(groups), T::COOP ? coarse : nullptr, coarse_shift);
     return hipGetLastError();
 }
 
@@ -301,7 +301,12 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 4; }
+int ggq_abi_version(void) { return 5; }
+
+#ifndef GGQ_BUILD_ID
+#define GGQ_BUILD_ID "unstamped"
+#endif
+const char* ggq_build_id(void) { return GGQ_BUILD_ID; }
 
 int ggq_supported(int qtype) { return find_format(qtype) ? 1 : 0; }
 

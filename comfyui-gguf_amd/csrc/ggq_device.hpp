@@ -71,7 +71,8 @@ GGQ_DEV _Float16 lds_h(const uint8_t* p) { return __builtin_bit_cast(_Float16, *
 // aligned formats).  So, when the bytes are in LDS: read the enclosing ALIGNED dwords -- volatile
 // on an explicit LDS-address-space pointer, so that they stay separate ds_read_b32 -- and
 // funnel-shift them into place with v_alignbyte_b32.  (LDS = false: the same code pointed at
-// global memory, where a misaligned load costs nothing; used only by the DIRECT engine.)
+// global memory, where a misaligned load costs nothing; used only by the harness's no-LDS engine,
+// tests/microbench/ggq_lab_engine.hpp.)
 typedef const volatile __attribute__((address_space(3))) uint32_t* lds_dword_ptr;
 GGQ_DEV uint32_t lds_dword(const uint8_t* p4) { return *(lds_dword_ptr)(p4); }
 
@@ -571,39 +572,30 @@ GGQ_DEV void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Launch shape: one wavefront = one group, start to finish, then the wave retires and the
-// hardware dispatcher starts the next workgroup -- no grid-stride loop.  (Measured on MI355X: a
-// persistent loop with a register prefetch of the next group is 10-15 % SLOWER, because its
-// s_waitcnt vmcnt(0) in front of the LDS fill also waits for the previous group's stores to be
-// acknowledged -- gfx950 counts loads and stores in the one vmcnt; profiles/r01_*.)
-//   F      block format            G      blocks per group
+// Launch shape: one team = one group, start to finish, then the waves retire and the hardware dispatcher starts the next
+// workgroup -- no grid-stride loop.  (Measured on MI355X: a persistent loop with a register prefetch of the next group is
+// 10-15 % SLOWER, because its s_waitcnt vmcnt(0) in front of the LDS fill also waits for the previous group's stores to be
+// acknowledged -- gfx950 counts loads and stores in the one vmcnt; a fully pipelined persistent engine is 17-25 % slower still;
+// profiles/r01_microbench_a/r.)  The experiment knobs those measurements needed (compile-time XCD mappings, a no-LDS engine, a store
+// throttle, several groups per wave, buffer loads with explicit cache policies) live in tests/microbench/ggq_lab_engine.hpp, not here.
+//   F      block format            G        blocks per group
 //   OUT    output dtype            NTL/NTS  non-temporal loads / stores
-//   WAVES  wavefronts per workgroup (they share nothing but the LDS allocation)
-// at most THR+1 store rows of a wave in flight (THR < 0: no throttle)
-template <int THR>
-GGQ_DEV void store_throttle()
-{
-    // s_waitcnt simm16 on gfx9: vmcnt = [3:0] | [15:14], expcnt = [6:4], lgkmcnt = [11:8]
-    if constexpr (THR >= 0) __builtin_amdgcn_s_waitcnt((THR & 15) | ((THR >> 4) << 14) | 0x0F70);
-}
-
-// SKEW: the tensor's base pointer itself may be only 2-byte aligned (a row inside a packed table): the misalignment of every
-// group start is then taken from the ADDRESS, not from the offset inside the tensor.
-// LPOL >= 0 (harness only): the group's bytes are fetched with BUFFER loads carrying that cache policy (aux bits: 1 = sc0, 2 = nt,
-// 16 = sc1) from a wave-uniform resource whose range ends at the tensor's last byte, instead of global loads with NTL.
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          bool SKEW = false, int LPOL = -1>
+//   WAVES  wavefronts per workgroup         ARITH  arithmetic mode (AR_*)
+//   COOP   the workgroup's waves own ONE group together (else: one group per wave, the waves share nothing but the LDS allocation)
+//   SKEW   the tensor's base pointer itself may be only 2-byte aligned (a row inside a packed table): the misalignment of every
+//          group start is then taken from the ADDRESS, not from the offset inside the tensor.
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false, bool SKEW = false>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
     static constexpr int GROUP_BYTES = G * TS;
     // A group starts 16-B aligned when GROUP_BYTES % 16 == 0 (any G that is a multiple of 8);
-    // otherwise its start is only MISALIGN_STEP-aligned and the wave loads from the aligned
+    // otherwise its start is only 2-byte aligned and the team loads from the aligned
     // address below it, keeping the same byte offset inside its LDS slice.
     static constexpr bool ALIGNED = GROUP_BYTES % 16 == 0 && !SKEW;
     static constexpr int UNITS = (GROUP_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;   // 16-B load units per group (max)
-    // TEAM = the threads that own one group: a wavefront, or (COOP) the whole workgroup -- then every wave stores ONE
-    // 1-KiB row instead of four back to back, which the memory system takes 6 % faster (tests/microbench `fillrows`).
+    // TEAM = the threads that own one group: a wavefront, or (COOP) the whole workgroup -- then every wave stores fewer
+    // 1-KiB rows back to back, which the memory system takes 6 % faster (tests/microbench `fillrows`).
     static constexpr int TEAM = COOP ? WAVES * 64 : 64;
     static constexpr int NU = (UNITS + TEAM - 1) / TEAM;   // loads per thread
     static constexpr int CHUNKS = G * CPB;
@@ -613,9 +605,8 @@ struct Engine {
     static constexpr int THREADS = WAVES * 64;
     static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
     static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
-    static_assert(!SKEW || (F::TS % F::LDS_ALIGN == 0 && !DIRECT), "a row start is a multiple of the block size only");
+    static_assert(!SKEW || F::TS % F::LDS_ALIGN == 0, "a row start is a multiple of the block size only");
     static_assert((CHUNKS * PIECES) % TEAM == 0, "a group must be a whole number of 1 KiB store rows per wave");
-    static_assert(!(COOP && DIRECT) && !(COOP && R != 1), "COOP is the LDS-staged single-pass engine");
 
     GGQ_DEV static void team_sync()
     {
@@ -637,13 +628,6 @@ struct Engine {
             if (left < (uint64_t)GROUP_BYTES) valid = a + (uint32_t)left;
         }
         u32x4 pf[NU];
-        if constexpr (LPOL >= 0) {
-            // raw buffer: units past the last one that holds valid bytes read as zero, so neither a bounds check nor a 64-bit address
-            // per lane (the range is rounded up to whole units: the same < 16-byte over-read inside an aligned unit as below)
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((valid + 15u) & ~15u), 0x00020000);
-#pragma unroll
-            for (int u = 0; u < NU; u++) pf[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((uint32_t)(lane + TEAM * u) * 16u), 0, LPOL);
-        } else
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const uint32_t o = (uint32_t)(lane + TEAM * u) * 16u;
@@ -669,101 +653,54 @@ struct Engine {
                 const Fields f = F::template fields<true>(slice + a + bl * TS, j);
                 emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
             }
-            if (s + 1 < NCH) store_throttle<THR>();
         }
     }
 
-    // DIRECT: no LDS staging -- every lane reads the few bytes its chunk needs straight from
-    // global memory (the same F::fields decode, pointed at the packed bytes).  A wave-row of 64 chunks
-    // touches 3-5 cache lines; neighbouring lanes share them through the vector L1.
-    template <bool FULL>
-    GGQ_DEV static void body_direct(const Work& w, int lane)
-    {
-        const uint64_t b0 = w.lg * (uint64_t)G;
-#pragma unroll
-        for (int s = 0; s < NCH; s++) {
-            const int unit = lane + 64 * s;
-            const int chunk = unit / PIECES, piece = unit % PIECES;
-            const int bl = chunk / CPB, j = chunk % CPB;
-            const uint64_t gb = b0 + (uint64_t)bl;
-            if (FULL || gb < w.n_blocks) {
-                const Fields f = F::template fields<false>((const uint8_t*)(w.packed + gb * (uint64_t)TS), j);
-                emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
-            }
-        }
-    }
-
-    // xrun_log2 (wave-uniform kernel argument, 0 = off): the run-length form of the XCD >= 2 mapping below,
-    // chosen per launch by the host (it pays on large launches only; profiles/r01_microbench_l_*).
+    // xrun_log2 (wave-uniform kernel argument, 0 = identity): the XCD-aware workgroup -> group mapping, chosen per launch by the
+    // host (it pays on large launches only; profiles/r01_microbench_l_*).
     template <class Locate>
     GGQ_DEV static void run(uint64_t total_groups, uint32_t xrun_log2, Locate locate)
     {
         // (the host may add untouched DYNAMIC LDS to a launch: it only caps how many workgroups a CU holds at once)
-        __shared__ __attribute__((aligned(16))) uint8_t smem[DIRECT ? 16 : (COOP ? 1 : WAVES) * SLICE];
+        __shared__ __attribute__((aligned(16))) uint8_t smem[(COOP ? 1 : WAVES) * SLICE];
         const int wave = COOP ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int lane = COOP ? (int)threadIdx.x : (int)(threadIdx.x & 63);
         uint32_t bid = blockIdx.x;
-        // workgroup b runs on XCD b % 8 (observed dispatch order; a speed hint only, never correctness)
-        if constexpr (XCD == 1) {
-            // give each XCD one contiguous eighth of the work instead of every eighth workgroup
-            const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = bid & 7u;
-            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-        } else if constexpr (XCD >= 2) {
-            // runs: inside every tile of 8*XCD consecutive workgroups, XCD x takes XCD CONSECUTIVE groups, so
-            // the 128-B line two neighbouring groups share (formats whose group size is not a multiple of
-            // 128 B) is fetched into ONE L2 instead of two; the tile as a whole still streams 8*XCD*4 KiB
-            // of output together.  The last, partial tile keeps the identity mapping.
-            constexpr uint32_t T = 8u * (uint32_t)XCD;
-            const uint32_t tile = bid / T, in = bid % T;
-            if ((tile + 1) * T <= gridDim.x) bid = tile * T + (in & 7u) * (uint32_t)XCD + (in >> 3);
-        } else if (xrun_log2 != 0) {
-            // What matters (profiles/r01_microbench_l/m/n): every XCD keeps the SAME slot of every tile (rotating the slot
-            // with the tile index loses 10 %; which XCD gets which slot is irrelevant, as is the walk direction).
+        // Workgroup b runs on XCD b % 8 (observed dispatch order; a speed hint only, never correctness).  Runs: inside every tile of
+        // 8 << xrun_log2 consecutive workgroups, XCD x takes (1 << xrun_log2) CONSECUTIVE groups, so the 128-B line two neighbouring
+        // groups share (formats whose group size is not a multiple of 128 B) is fetched into ONE L2 instead of two, while the tile as a
+        // whole still streams its output together.  What matters (profiles/r01_microbench_l/m/n): every XCD keeps the SAME slot of
+        // every tile (rotating the slot with the tile index loses 10 %; which XCD gets which slot is irrelevant, as is the walk
+        // direction).  The last, partial tile keeps the identity mapping.
+        if (xrun_log2 != 0) {
             const uint32_t tl = xrun_log2 + 3u, tile = bid >> tl, in = bid & ((1u << tl) - 1u);
             if (((tile + 1) << tl) <= gridDim.x) bid = (tile << tl) + ((in & 7u) << xrun_log2) + (in >> 3);
         }
         const uint64_t g = COOP ? (uint64_t)bid : (uint64_t)bid * WAVES + (uint64_t)wave;
         if (g >= total_groups) return;
-        const Work w0 = locate(g);                       // lg counts units of R*G blocks
-        uint8_t* slice = smem + (DIRECT ? 0 : wave * SLICE);          // COOP: wave == 0, one slice per workgroup
-        // R > 1: the wave walks R consecutive groups strictly one after the other -- load, unpack,
-        // store, wait for the store -- so it never has more than one group's traffic in flight.
-#pragma unroll 1
-        for (int r = 0; r < R; r++) {
-            Work w = w0;
-            w.lg = w0.lg * (uint64_t)R + (uint64_t)r;
-            if (r > 0 && w.lg * (uint64_t)G >= w.n_blocks) break;
-            const bool full = (w.lg + 1) * (uint64_t)G <= w.n_blocks;
-            if constexpr (DIRECT) {
-                if (full) body_direct<true>(w, lane); else body_direct<false>(w, lane);
-            } else {
-                if (full) body<true>(slice, w, lane); else body<false>(slice, w, lane);
-            }
-            if (r + 1 < R) {
-                store_throttle<0>();
-                wave_sync();
-            }
-        }
+        const Work w = locate(g);
+        uint8_t* slice = smem + wave * SLICE;             // COOP: wave == 0, one slice per workgroup
+        if ((w.lg + 1) * (uint64_t)G <= w.n_blocks) body<true>(slice, w, lane);
+        else body<false>(slice, w, lane);
     }
 };
 
 // one tensor, descriptor by value
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total_groups, uint32_t xrun_log2)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
+    Engine<F, G, OUT, NTL, NTS, WAVES, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) { return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g}; });
 }
 
 // many tensors of one format: table in device memory, sorted by first_group.  Finding the tensor of group g is a chain
 // of DEPENDENT scalar loads at the head of every wave: `coarse[c]` (optional) = the entry that holds group c << coarse_shift,
 // which leaves a 1-2 step forward scan instead of a log2(n)-step binary search -- a team holds its wave slots idle during
 // that chain, which costs the multi-wave (COOP) teams most (tests/microbench `ablocate`).
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          int LPOL = -1>
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2,
                                                            const uint32_t* __restrict__ coarse, uint32_t coarse_shift)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL>::run(total_groups, xrun_log2, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0;                                // last entry with first_group <= g
         if (coarse != nullptr) {
             lo = coarse[g >> coarse_shift];
@@ -791,7 +728,7 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_rows(const uint8_t* __rest
 {
     constexpr uint64_t OUT_BYTES = (OUT == OUT_F32) ? 4 : 2;
     const uint64_t t = blockIdx.y;
-    Engine<F, G, OUT, NTL, NTS, WAVES, 0, false, -1, 1, ARITH, COOP, true>::run(groups_per_row, 0u, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, ARITH, COOP, true>::run(groups_per_row, 0u, [&](uint64_t g) {
         int64_t row = indices[t];
         row = row < 0 ? 0 : (row >= (int64_t)n_rows ? (int64_t)n_rows - 1 : row);
         return Work{(gcptr)packed + (uint64_t)row * row_blocks * (uint64_t)F::TS, (gptr)out + t * row_blocks * (uint64_t)F::BS * OUT_BYTES,

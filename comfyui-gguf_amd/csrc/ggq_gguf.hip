@@ -396,6 +396,16 @@ int ggq_gguf_upload(const ggq_gguf* g, void* dev_dst, uint64_t offset, uint64_t 
         }
     }
 
+    // dev_dst comes from the caller's allocator on the caller's stream: a caching allocator may hand out a block that kernels
+    // ALREADY QUEUED on that stream still read or write (a model swapped in one process).  The workers copy on private
+    // non-blocking streams, so each of them first waits for everything the caller's stream holds at this point.
+    hipEvent_t entry = nullptr;
+    if (hipEventCreateWithFlags(&entry, hipEventDisableTiming) != hipSuccess) return GGQ_ERR_HIP;
+    if (hipEventRecord(entry, static_cast<hipStream_t>(hip_stream)) != hipSuccess) {
+        (void)hipEventDestroy(entry);
+        return GGQ_ERR_HIP;
+    }
+
     std::atomic<int> status{GGQ_OK};
     std::vector<hipEvent_t> done((size_t)threads, nullptr);
     auto worker = [&](int t) {
@@ -404,6 +414,7 @@ int ggq_gguf_upload(const ggq_gguf* g, void* dev_dst, uint64_t offset, uint64_t 
         hipEvent_t ev[DEPTH] = {};
         bool used[DEPTH] = {};
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { status = GGQ_ERR_HIP; return; }
+        if (hipStreamWaitEvent(s, entry, 0) != hipSuccess) status = GGQ_ERR_HIP;
         for (int d = 0; d < DEPTH; d++)
             if (hipEventCreateWithFlags(&ev[d], hipEventDisableTiming) != hipSuccess) status = GGQ_ERR_HIP;
         uint64_t it = 0;
@@ -436,6 +447,7 @@ int ggq_gguf_upload(const ggq_gguf* g, void* dev_dst, uint64_t offset, uint64_t 
     try {
         pool.reserve((size_t)threads);
     } catch (...) {
+        (void)hipEventDestroy(entry);
         return GGQ_ERR_NOMEM;
     }
     for (int t = 0; t < threads; t++) {
@@ -447,6 +459,7 @@ int ggq_gguf_upload(const ggq_gguf* g, void* dev_dst, uint64_t offset, uint64_t 
         }
     }
     for (std::thread& th : pool) th.join();
+    (void)hipEventDestroy(entry);
     for (hipEvent_t e : done) {
         if (!e) continue;
         if (status == GGQ_OK && hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), e, 0) != hipSuccess) status = GGQ_ERR_HIP;

@@ -87,6 +87,23 @@ except AttributeError:                                     # torch built without
 _NoTorchFunction = torch._C.DisableTorchFunctionSubclass
 _ggq_dequant = None
 
+# libggq_hip.so holds gfx950 code objects only.  A GPU of any other architecture (another AMD part, or an NVIDIA device in a
+# CUDA build of torch) is "not served here", exactly like a CPU tensor: GGQUnsupported, so that under install() the reference's
+# own torch path keeps working on it instead of a failing kernel launch.  Checked once per device index.
+_DEVICE_OK = {}
+
+
+def _device_served(index):
+    ok = _DEVICE_OK.get(index)
+    if ok is None:
+        arch = getattr(torch.cuda.get_device_properties(index), "gcnArchName", "") or ""
+        ok = _DEVICE_OK[index] = arch.split(":")[0] == "gfx950"
+        if not ok:
+            import logging
+            logging.warning(f"comfyui-gguf_amd: cuda:{index} is {arch or 'not an AMD GPU'}; the HIP kernels are gfx950 (MI355X) only -- "
+                            "requests on that device keep the reference's torch path")
+    return ok
+
 
 def _launch(qtype, data, n_blocks, out, compute_code, out_code):
     """Enqueue on torch's CURRENT stream of data's device: orders after the H2D copy, before F.linear."""
@@ -94,6 +111,8 @@ def _launch(qtype, data, n_blocks, out, compute_code, out_code):
     if _ggq_dequant is None:
         _ggq_dequant = _native.lib().ggq_dequant
     index = data.device.index
+    if not (_DEVICE_OK.get(index) or _device_served(index)):
+        raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
     if _cur_device() != index:
         with torch.cuda.device(index):
             return _launch(qtype, data, n_blocks, out, compute_code, out_code)
@@ -254,6 +273,8 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
         out = torch.empty(tuple(indices.shape) + (cols,), dtype=out_dtype, device=data.device)
         if idx.numel():
             index = data.device.index
+            if not (_DEVICE_OK.get(index) or _device_served(index)):
+                raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
             with torch.cuda.device(index):
                 rc = _native.lib().ggq_dequant_rows(qid, data.data_ptr(), n_rows, cols // block_size, idx.data_ptr(), idx.numel(), out.data_ptr(),
                                                     compute_code, _OUT_CODE[out_dtype], _raw_stream(index))

@@ -13,7 +13,7 @@ fp32 summation order -- parity is a tolerance against an fp32 reference (tests/t
 import torch
 
 from . import _native
-from .dequant import GGQUnsupported, _HIP_TABLE, _OUT_CODE, _qtype_key, _raw_stream, dequantize_tensor, is_quantized
+from .dequant import GGQUnsupported, _DEVICE_OK, _HIP_TABLE, _OUT_CODE, _device_served, _qtype_key, _raw_stream, dequantize_tensor, is_quantized
 
 MAX_ROWS = 4
 
@@ -23,8 +23,9 @@ def linear_small(x, weight, bias=None, dequant_dtype=None):
     Raises GGQUnsupported for anything the kernel does not take (the caller keeps dequantize + F.linear)."""
     if dequant_dtype not in (None, torch.float16):
         raise GGQUnsupported("the fused linear computes the stock fp16 weight values only")
-    if getattr(weight, "patches", None):
-        raise GGQUnsupported("LoRA-patched weight: needs the dense tensor")
+    if getattr(weight, "patches", None) or getattr(bias, "patches", None):
+        # get_weight applies LoRA patches to the weight AND to the bias (ops.py:183-190 via ops.py:205-206)
+        raise GGQUnsupported("LoRA-patched weight or bias: needs the reference's get_weight")
     qtype = getattr(weight, "tensor_type", None)
     key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
     if key not in _HIP_TABLE:
@@ -48,8 +49,10 @@ def linear_small(x, weight, bias=None, dequant_dtype=None):
     with torch._C.DisableTorchFunctionSubclass():
         if weight.dtype is not torch.uint8 or not weight.is_contiguous() or weight.data_ptr() & 15:
             raise GGQUnsupported("packed weight must be a contiguous, 16-byte aligned byte tensor")
-        y = torch.empty((m, rows), dtype=x.dtype, device=x.device)
         index = x.device.index
+        if not (_DEVICE_OK.get(index) or _device_served(index)):
+            raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
+        y = torch.empty((m, rows), dtype=x.dtype, device=x.device)
         with torch.cuda.device(index):
             rc = _native.lib().ggq_linear_small(_HIP_TABLE[key][0], weight.data_ptr(), rows, cols, xf.data_ptr(), m,
                                                 None if bias is None else bias.data_ptr(), y.data_ptr(), _OUT_CODE[x.dtype], _raw_stream(index))

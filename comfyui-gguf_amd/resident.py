@@ -18,6 +18,13 @@ caller in the reference that writes into the dequantized weight, the LoRA branch
 An entry is valid for exactly one packed tensor OBJECT in one state: it is keyed by ``id(tensor)``, holds a
 weak reference to it (a recycled id never matches, and the entry dies with the tensor) and records the
 tensor's in-place version counter (a ``copy_`` into the packed bytes invalidates it).
+
+Low-VRAM mode (weights kept on the CPU, ``s.weight.to(device)`` on every forward, ops.py:209): ``GGMLTensor.to`` hands out
+a NEW tensor object per forward (ops.py:57-62), so nothing can ever hit -- every entry dies, unused, with the temporary it
+was keyed on.  The cache notices (``EPHEMERAL_STREAK`` entries in a row that died without a single hit) and stands aside:
+it stops inserting and only probes every ``PROBE_EVERY``-th call, so that mode pays one integer compare per call instead of
+the bookkeeping.  Any hit ends the streak.  (A packed byte address is not a usable key there: the caching allocator recycles
+the addresses of those temporaries between layers.)
 """
 import collections
 import weakref
@@ -25,14 +32,20 @@ import weakref
 import torch
 
 
+EPHEMERAL_STREAK = 16      # entries in a row that died without a hit -> the callers hand in per-call temporaries
+PROBE_EVERY = 64           # ... then only every 64th cacheable call is inserted, to notice when that changes
+
+
 class DenseCache:
     def __init__(self, budget_bytes, dequantize_tensor, require_gpu=True):
         self.budget = int(budget_bytes)
         self._fn = dequantize_tensor
         self._require_gpu = require_gpu               # False only in the CPU unit tests of the bookkeeping
-        self._entries = collections.OrderedDict()     # key -> (weakref to packed tensor, version, dense)
+        self._entries = collections.OrderedDict()     # key -> [weakref to packed tensor, version, dense, hits]
         self.bytes = 0
-        self.hits = self.misses = self.bypassed = 0
+        self.hits = self.misses = self.bypassed = self.ephemeral_bypassed = 0
+        self._streak = 0                              # consecutive entries that died with their tensor, never hit
+        self._calls_while_aside = 0
 
     @staticmethod
     def _nbytes(t):
@@ -43,9 +56,16 @@ class DenseCache:
         if ent is not None:
             self.bytes -= self._nbytes(ent[2])
 
+    def _tensor_died(self, key):
+        ent = self._entries.get(key)
+        if ent is not None:
+            self._streak = self._streak + 1 if ent[3] == 0 else 0
+        self._drop(key)
+
     def clear(self):
         self._entries.clear()
         self.bytes = 0
+        self._streak = 0
 
     def __call__(self, tensor, dtype=None, dequant_dtype=None):
         # not cacheable: anything that is not a quantized GGML tensor living on a GPU, or one with LoRA patches
@@ -59,8 +79,15 @@ class DenseCache:
             if ent[0]() is tensor and ent[1] == tensor._version:
                 self._entries.move_to_end(key)
                 self.hits += 1
+                ent[3] += 1
+                self._streak = 0
                 return ent[2]
             self._drop(key)
+        if self._streak >= EPHEMERAL_STREAK:           # low-VRAM mode: a fresh tensor object per forward, nothing to hit
+            self._calls_while_aside += 1
+            if self._calls_while_aside % PROBE_EVERY:
+                self.ephemeral_bypassed += 1
+                return self._fn(tensor, dtype, dequant_dtype)
         dense = self._fn(tensor, dtype, dequant_dtype)
         self.misses += 1
         if not isinstance(dense, torch.Tensor) or dense.data_ptr() == tensor.data_ptr():
@@ -70,10 +97,11 @@ class DenseCache:
             return dense
         while self.bytes + size > self.budget and self._entries:
             self._drop(next(iter(self._entries)))      # least recently used first
-        ref = weakref.ref(tensor, lambda _r, k=key: self._drop(k))
-        self._entries[key] = (ref, tensor._version, dense)
+        ref = weakref.ref(tensor, lambda _r, k=key: self._tensor_died(k))
+        self._entries[key] = [ref, tensor._version, dense, 0]
         self.bytes += size
         return dense
 
     def stats(self):
-        return {"entries": len(self._entries), "bytes": self.bytes, "hits": self.hits, "misses": self.misses, "bypassed": self.bypassed}
+        return {"entries": len(self._entries), "bytes": self.bytes, "hits": self.hits, "misses": self.misses, "bypassed": self.bypassed,
+                "ephemeral_bypassed": self.ephemeral_bypassed}

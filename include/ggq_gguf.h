@@ -107,7 +107,9 @@ int ggq_ggml_type_geometry(int qtype, uint32_t* block_size, uint32_t* type_size)
  * pinned staging buffers and copied host->device in `chunk_bytes` pieces on internal streams, reads
  * of chunk k+1 overlapping the DMA of chunk k.  Load-time call: returns when every byte has landed;
  * additionally `hip_stream` is made to wait for the copies, so work enqueued on it afterwards is
- * ordered without relying on the host-side wait.  threads <= 0 / chunk_bytes == 0 pick defaults
+ * ordered without relying on the host-side wait; and the copies themselves start only after everything
+ * already enqueued on `hip_stream` at entry (dev_dst may be a recycled block of a caching allocator that
+ * queued kernels still touch).  threads <= 0 / chunk_bytes == 0 pick defaults
  * (8 threads, 16 MiB).  Replaces: `s.weight.to(device)` per layer on every forward in low-VRAM mode
  * (ops.py:209) by ONE sequential pass at load time -- 288 GB of HBM holds any supported model whole. */
 int ggq_gguf_upload(const ggq_gguf* g, void* dev_dst, uint64_t offset, uint64_t nbytes, int threads, uint64_t chunk_bytes,

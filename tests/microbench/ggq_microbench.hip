@@ -6,6 +6,7 @@
 //      straight from ggq_device.hpp, over a working set >> the 256 MiB Infinity Cache.
 // Build: see tests/microbench/Makefile.   Run: ./ggq_microbench [parity|ceil|variants|formats|all]
 #include "../../comfyui-gguf_amd/csrc/ggq_device.hpp"
+#include "ggq_lab_engine.hpp"      // the engine with its experiment knobs (XCD / DIRECT / THR / R / LPOL): ggq::lab
 #include "ggq_stream.hpp"
 #include "../../include/ggq.h"
 
@@ -401,7 +402,7 @@ static bool check_variant()
         HIP_CHECK(hipMemcpy(dp, packed.data(), packed.size(), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemset(dout, 0xCD, n * F::BS * 2 + 256));
         const uint64_t groups = (n + G * R - 1) / (G * R);
-        hipLaunchKernelGGL((ggq::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+        hipLaunchKernelGGL((ggq::lab::dequant_one<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
                            ggq::Desc{dp, dout, n, 0}, groups, 0u);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
@@ -424,7 +425,7 @@ static void time_variant(const char* name, Pool& P, Timer& T)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     double med, mn;
-    T.run([&] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u); }, 3, 31, med, mn);
+    T.run([&] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u); }, 3, 31, med, mn);
     const double bytes = (double)P.elements * (2.0 + (double)P.ts / P.bs);
     printf("VAR %-6s %s thr=%-2d G=%-3d ntl=%d nts=%d waves=%-2d xcd=%d grid=%-7llu  %7.3f ms  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f GB/s  parity=%s\n", name, DIRECT ? "direct" : "lds   ", THR, G, (int)NTL, (int)NTS, WAVES, (int)XCD,
            (unsigned long long)blocks, med, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6, ok ? "ok" : "MISMATCH");
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_skel(const ggq::u32x4* __restric
     for (int s = 0; s < NST; s++) {
         ggq::u32x4 v = acc; v.y += s;
         if (NT) __builtin_nontemporal_store(v, out + (w * NST + s) * 64 + lane); else out[(w * NST + s) * 64 + lane] = v;
-        if (s + 1 < NST) ggq::store_throttle<THR>();
+        if (s + 1 < NST) ggq::lab::store_throttle<THR>();
     }
     if (DEP == 2) {
 #pragma unroll
@@ -545,7 +546,7 @@ static void launch3(Pool& P)
     HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
     const uint64_t blocks = (groups + WAVES - 1) / WAVES;
     for (int i = 0; i < 3; i++)
-        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u);
+        hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, dt, (uint32_t)d.size(), groups, 0u, nullptr, 0u);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipFree(dt));
 }
@@ -618,8 +619,8 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
     const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
     char buf[160];
     snprintf(buf, sizeof buf, "%s %s G=%dx%d ntl=%d nts=%d waves=%d xcd=%d xrun=%u thr=%d dynlds=%dK", name, COOP ? "coop" : (DIRECT ? "direct" : "lds"), G, R, (int)NTL, (int)NTS, WAVES, XCD, xrun, THR, dyn_lds / 1024);
-    if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
-    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun, nullptr, 0u); },
+    if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun, nullptr, 0u); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R, COOP>()});
 }
 
@@ -1023,7 +1024,7 @@ static bool check_lpol()
         const uint64_t groups = (n + G - 1) / G;
         const ggq::Desc tab[1] = {{dp, dout, n, 0}};
         ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, sizeof tab)); HIP_CHECK(hipMemcpy(dt, tab, sizeof tab, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
+        hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), 0, nullptr,
                            dt, 1u, groups, 0u, nullptr, 0u);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(got.data(), dout, n * F::BS * 2, hipMemcpyDeviceToHost));
@@ -1047,7 +1048,7 @@ static void ab_add_lpol(AB& ab, const char* name, Pool& P, uint32_t xrun)
     const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
     char buf[160];
     snprintf(buf, sizeof buf, "%s %s G=%d buffer loads%s%s%s xrun=%u", name, COOP ? "coop" : "solo", G, (LPOL & 1) ? " sc0" : "", (LPOL & 16) ? " sc1" : "", (LPOL & 2) ? " nt" : "", xrun);
-    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3(blocks), dim3(WAVES * 64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u); },
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, false, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, LPOL>), dim3(blocks), dim3(WAVES * 64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_lpol<F, G, WAVES, COOP, LPOL>()});
 }
 

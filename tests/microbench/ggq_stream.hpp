@@ -36,7 +36,7 @@ GGQ_DEV void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<
 // address and store to `trash` (>= 4 KiB of device memory nobody reads) instead of being masked off.
 template <class F, int G, int OUT, bool NTL, bool NTS, int D, int ARITH = AR_F16>
 struct StreamEngine {
-    using E = Engine<F, G, OUT, NTL, NTS, 1, 0, false, -1, 1, ARITH, false>;
+    using E = Engine<F, G, OUT, NTL, NTS, 1, ARITH, false>;
     static constexpr int TS = F::TS, BS = F::BS, CPB = E::CPB, NU = E::NU, NCH = E::NCH, SLICE = E::SLICE, PIECES = E::PIECES;
     static constexpr int GROUP_BYTES = E::GROUP_BYTES;
     static constexpr bool ALIGNED = E::ALIGNED;

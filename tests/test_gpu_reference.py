@@ -1,0 +1,253 @@
+"""install() over the REFERENCE's real classes with GPU-resident weights (Missing #2 / Weak #1).
+
+The reference's ``dequant.py`` and ``ops.py`` are executed verbatim (oracle/reference.py: /root/reference in the build
+container, the staged copy oracle/_ref on the GPU box -- oracle/stage_reference.py) over the fake ``comfy`` of
+oracle/fake_comfy.py.  Their ``GGMLTensor`` (``__new__/__init__`` pair, ``__torch_function__`` subclass, ops.py:44-91) holds CUDA
+bytes, their ``GGMLOps.Linear / Embedding / Conv2d / LayerNorm`` call ``get_weight`` / ``cast_bias_weight`` (ops.py:166-211), and
+underneath, ``install()`` has swapped in the HIP path.  Every result is compared
+
+  * with the reference's OWN torch ops executed on the same GPU tensors (the ``uninstall()`` side), bit for bit, and
+  * with the C oracle (which is pinned to the reference's CPU results),
+
+and every "installed" call is checked to have really launched a HIP kernel (no silent fall-through).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import reference
+
+import ref_harness as H
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not reference.available(), reason="reference sources neither live nor staged (oracle/stage_reference.py)")]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def mods(monkeypatch):
+    if reference.source() == "staged-UNVERIFIED":
+        pytest.fail("oracle/_ref does not match its MANIFEST.json: restage with oracle/stage_reference.py")
+    return reference.load_reference_package("ggq_refgpu", setitem=monkeypatch.setitem)
+
+
+def test_reference_modules_are_the_real_ones(mods, pkg):
+    rd, ro = mods["dequant"], mods["ops"]
+    assert rd.__file__.startswith(reference.REFERENCE_DIR) and ro.__file__.startswith(reference.REFERENCE_DIR)
+    assert ro.GGMLTensor is not pkg.ops.GGMLTensor and issubclass(ro.GGMLOps.Linear, ro.GGMLLayer)
+    assert ro.dequantize_tensor is rd.dequantize_tensor
+
+
+@pytest.mark.parametrize("qname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"])
+def test_dequantize_tensor_on_reference_ggmltensor_cuda(mods, pkg, dev, monkeypatch, qname):
+    """12 formats x dequant_dtype in {None, "target", fp32, bf16} x dtype in {fp16, bf16, fp32} x {nominal, signed,
+    adversarial} scales: reference torch ops on the GPU == HIP path == oracle."""
+    rd, ro = mods["dequant"], mods["ops"]
+    q = pkg.qtypes.Q[qname]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    rows, cols = 6, 3 * 256                                  # ragged against every group size (2048 / 4096 elements)
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    for mode in ("nominal", "signed", "adversarial"):
+        packed = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=11, mode=mode)
+        w = H.ggml(ro, packed, q, (rows, cols), dev, rows=rows)
+        assert type(w) is ro.GGMLTensor and w.is_cuda and tuple(w.shape) == (rows, cols) and w.size(0) == rows
+        for dd in H.DEQUANT_DTYPES:
+            for dtype in H.DTYPES:
+                want = rd.dequantize_tensor(w, dtype, dd)    # the reference's eager torch ops, on the GPU
+                before = counter.n
+                with H.Installed(pkg, mods):
+                    got = rd.dequantize_tensor(w, dtype, dd)
+                    also = ro.dequantize_tensor(w, dtype, dd)   # the name ops.py bound at import
+                assert counter.n == before + 2, "install() did not route the GPU tensor to the HIP kernels"
+                assert type(got) is torch.Tensor or isinstance(got, torch.Tensor)
+                assert H.same_bits(got, want), (qname, mode, dd, dtype)
+                assert H.same_bits(also, want)
+                assert H.same_bits(got, H.oracle_tensor(q, packed, dtype, dd, (rows, cols))), (qname, mode, dd, dtype, "oracle")
+    # dequantize() itself (dequant.py:30): the block-level entry with the arithmetic dtype
+    packed = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=12, mode="signed")
+    w = H.ggml(ro, packed, q, (rows, cols), dev, rows=rows)
+    for dd in (None, torch.float16, torch.bfloat16, torch.float32):
+        want = rd.dequantize(w.data, q, w.tensor_shape, dtype=dd)
+        with H.Installed(pkg, mods):
+            got = rd.dequantize(w.data, q, w.tensor_shape, dtype=dd)
+        assert H.same_bits(got, want), (qname, dd)
+
+
+@pytest.mark.parametrize("qname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"])
+@pytest.mark.parametrize("resident", [True, False], ids=["weights-on-gpu", "lowvram-cpu-weights"])
+def test_reference_linear_forward(mods, pkg, dev, monkeypatch, qname, resident):
+    """GGMLOps.Linear.forward (ops.py:213-244) with install() underneath: same output as the reference's own path on the same
+    device tensors, for resident weights and for the low-VRAM mode (CPU weights, ``s.weight.to(device)`` per forward, ops.py:209),
+    LoRA-patched and unpatched, in every dequant_dtype."""
+    ro = mods["ops"]
+    q = pkg.qtypes.Q[qname]
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    wdev = dev if resident else "cpu"
+    for dd in H.DEQUANT_DTYPES:
+        for patched in (False, True):
+            patches = H.lora_patch((24, 512), seed=5) if patched else None
+            lin, packed = H.make_linear(ro, pkg, q, 24, 512, wdev, seed=21, patches=patches, dequant_dtype=dd)
+            for dtype, m in ((torch.bfloat16, 3), (torch.float16, 70), (torch.float32, 1)):
+                x = torch.randn(m, 512, device=dev, dtype=dtype, generator=torch.Generator(device=dev).manual_seed(m))
+                want = lin(x)
+                before = counter.n
+                with H.Installed(pkg, mods):
+                    got = lin(x)
+                    again = lin(x)
+                assert counter.n == before + 2
+                assert type(got) is torch.Tensor and got.dtype == dtype and got.shape == (m, 24)
+                assert torch.equal(got, want) and torch.equal(again, want), (qname, dd, patched, dtype)
+                # ... and F.linear on the oracle's weight (+ the same in-place LoRA update) is the same tensor
+                if not patched:
+                    wref = H.oracle_tensor(q, packed, dtype, dd, (24, 512)).to(dev)
+                    b = torch.Tensor(lin.bias).to(device=dev, dtype=dtype)
+                    assert torch.equal(got, torch.nn.functional.linear(x, wref, b)), (qname, dd, dtype, "oracle")
+
+
+def test_reference_linear_patched_weight_is_patched(mods, pkg, dev):
+    """The LoRA branch of get_weight (ops.py:183-190) runs on top of the HIP result: the patch is applied, in place, to OUR tensor."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    plain, packed = H.make_linear(ro, pkg, Q.Q4_K, 16, 256, dev, seed=3, bias=False)
+    lora, _ = H.make_linear(ro, pkg, Q.Q4_K, 16, 256, dev, seed=3, bias=False, patches=H.lora_patch((16, 256), seed=9, strength=1.0))
+    with H.Installed(pkg, mods):
+        w0 = plain.get_weight(plain.weight, torch.float32)
+        w1 = lora.get_weight(lora.weight, torch.float32)
+    diff = H.lora_patch((16, 256), seed=9)[0][0][0][1].to(dev)
+    assert torch.equal(w1, w0 + diff) and not torch.equal(w1, w0)
+
+
+@pytest.mark.parametrize("resident", [True, False], ids=["weights-on-gpu", "lowvram-cpu-weights"])
+def test_reference_linear_with_dense_cache(mods, pkg, dev, monkeypatch, resident):
+    """install(dense_cache_gb=...): same values; a resident weight is dequantized once, a LoRA-patched one every time (its
+    dense tensor is patched in place), and in low-VRAM mode -- a fresh GGMLTensor per forward -- the cache stands aside."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    wdev = dev if resident else "cpu"
+    lin, _ = H.make_linear(ro, pkg, Q.Q5_K, 32, 512, wdev, seed=2)
+    lora, _ = H.make_linear(ro, pkg, Q.Q5_K, 32, 512, wdev, seed=2, patches=H.lora_patch((32, 512), seed=8))
+    x = torch.randn(5, 512, device=dev, dtype=torch.bfloat16)
+    want, want_lora = lin(x), lora(x)
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    with H.Installed(pkg, mods, dense_cache_gb=1) as inst:
+        for _ in range(40):
+            assert torch.equal(lin(x), want)
+        for _ in range(3):
+            assert torch.equal(lora(x), want_lora)             # never served from (or written into) the cache
+        st = inst.cache.stats()
+    if resident:
+        assert counter.n == 1 + 3 and st["hits"] == 39 and st["entries"] == 1
+    else:
+        assert counter.n == 40 + 3 and st["hits"] == 0 and st["entries"] == 0
+        assert st["ephemeral_bypassed"] > 0                      # detected: per-forward copies are not worth caching
+
+
+def test_reference_linear_fused_small_m(mods, pkg, dev, monkeypatch):
+    """install(fused_small_m=True): m > 4 rows and LoRA-patched weights (weight OR bias) keep the reference's method bit for bit;
+    m <= 4 goes through the fused kernel and matches to fp32-summation tolerance."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, packed = H.make_linear(ro, pkg, Q.Q4_K, 48, 1024, dev, seed=4)
+    lora, _ = H.make_linear(ro, pkg, Q.Q4_K, 48, 1024, dev, seed=4, patches=H.lora_patch((48, 1024), seed=6))
+    blora, _ = H.make_linear(ro, pkg, Q.Q4_K, 48, 1024, dev, seed=4)
+    blora.bias.patches = H.lora_patch((48,), seed=7, strength=1.0)
+    xs = {m: torch.randn(m, 1024, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(m)) for m in (1, 4, 9)}
+    want = {m: lin(x) for m, x in xs.items()}
+    want_lora = {m: lora(x) for m, x in xs.items()}
+    want_blora = {m: blora(x) for m, x in xs.items()}
+    assert not torch.equal(want_blora[1], want[1])
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    with H.Installed(pkg, mods, fused_small_m=True):
+        assert torch.equal(lin(xs[9]), want[9]) and counter.n == 1          # dequantize + F.linear
+        for m in (1, 4):
+            got = lin(xs[m])
+            assert counter.n == 1, "the fused kernel reads the packed weight itself"
+            w64 = H.oracle_tensor(Q.Q4_K, packed, torch.bfloat16, None, (48, 1024)).double()
+            ref = xs[m].cpu().double() @ w64.T + torch.Tensor(lin.bias).cpu().double()
+            tol = 1024 * 2.0 ** -24 * (xs[m].cpu().double().abs() @ w64.abs().T) + 2.0 ** -8 * ref.abs() + 1e-30
+            assert bool(((got.cpu().double() - ref).abs() <= tol).all())
+        n = counter.n
+        for m in (1, 4, 9):
+            assert torch.equal(lora(xs[m]), want_lora[m])                    # patched weight: the reference's method
+            assert torch.equal(blora(xs[m]), want_blora[m])                  # patched BIAS alone: too
+        assert counter.n == n + 6
+
+
+@pytest.mark.parametrize("qname", ["Q4_0", "Q8_0", "Q4_K", "Q6_K", "IQ4_XS"])
+@pytest.mark.parametrize("gather", [False, True], ids=["two-step", "gather_embedding"])
+def test_reference_embedding_forward(mods, pkg, dev, monkeypatch, qname, gather):
+    ro = mods["ops"]
+    q = pkg.qtypes.Q[qname]
+    for dd in (None, "target", torch.float32):
+        emb, packed = H.make_embedding(ro, pkg, q, 40, 512, dev, seed=13, dequant_dtype=dd)
+        ids = torch.tensor([[0, 39, 7, 7, 12]], device=dev)
+        for out_dtype in (None, torch.float32, torch.bfloat16, torch.float16):
+            want = emb(ids, out_dtype=out_dtype)
+            counter = H.LaunchCounter(pkg, monkeypatch)
+            calls = []
+            if gather:
+                real = pkg.dequant.dequantize_rows
+                monkeypatch.setattr(pkg.dequant, "dequantize_rows", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+            with H.Installed(pkg, mods, gather_embedding=gather):
+                got = emb(ids, out_dtype=out_dtype)
+            assert (len(calls) == 1 and counter.n == 0) if gather else counter.n == 1
+            assert got.dtype == want.dtype and torch.equal(got, want), (qname, dd, out_dtype, gather)
+
+
+def test_reference_conv2d_and_layernorm(mods, pkg, dev, monkeypatch):
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    conv, packed = H.make_conv2d(ro, pkg, Q.Q5_0, 16, 8, 4, 4, dev, seed=17)
+    x = torch.randn(2, 8, 12, 12, device=dev, dtype=torch.float16)
+    want = conv(x)
+    with H.Installed(pkg, mods):
+        got = conv(x)
+    assert counter.n == 1 and torch.equal(got, want)
+    wref = H.oracle_tensor(Q.Q5_0, packed, torch.float16, None, (16, 8, 4, 4)).to(dev)
+    assert torch.equal(got, torch.nn.functional.conv2d(x, wref, torch.Tensor(conv.bias).to(dev, torch.float16), padding=1))
+    # BF16-typed GGMLTensor parameters (ggml type 30: "quantized" for the reference, a bit reinterpretation for us)
+    ln = ro.GGMLOps.LayerNorm(256, device="meta")
+    g = torch.Generator().manual_seed(1)
+    wb = torch.randn(256, generator=g).to(torch.bfloat16)
+    ln.weight = H.param(H.ggml(ro, wb.view(torch.int16).numpy().view(np.uint8), Q.BF16, (256,), dev))
+    ln.bias = H.param(H.ggml(ro, torch.randn(256, generator=g).numpy(), Q.F32, (256,), dev))
+    y = torch.randn(4, 256, device=dev, dtype=torch.float32)
+    want = ln(y)
+    with H.Installed(pkg, mods):
+        got = ln(y)
+    assert torch.equal(got, want)
+    assert torch.equal(got, torch.nn.functional.layer_norm(y, (256,), wb.float().to(dev), torch.Tensor(ln.bias).to(dev), ln.eps))
+
+
+def test_module_to_device_then_forward(mods, pkg, dev, monkeypatch):
+    """What ComfyUI's model patcher does: build the module with CPU GGMLTensor parameters, ``module.to(device)`` (Parameter
+    re-wrapping of a Tensor subclass, GGMLTensor.to re-attaching the attrs), then forward."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, packed = H.make_linear(ro, pkg, Q.Q6_K, 24, 512, "cpu", seed=31)
+    lin = lin.to(dev)
+    assert type(lin.weight) is ro.GGMLTensor and lin.weight.is_cuda and lin.weight.tensor_type == Q.Q6_K and tuple(lin.weight.shape) == (24, 512)
+    x = torch.randn(7, 512, device=dev, dtype=torch.bfloat16)
+    want = lin(x)
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    with H.Installed(pkg, mods):
+        got = lin(x)
+    assert counter.n == 1 and torch.equal(got, want)
+    assert torch.equal(got, torch.nn.functional.linear(x, H.oracle_tensor(Q.Q6_K, packed, torch.bfloat16, None, (24, 512)).to(dev),
+                                                       torch.Tensor(lin.bias).to(dev, torch.bfloat16)))
+
+
+def test_torch_compile_through_reference_linear(mods, pkg, dev):
+    """The reference allows full compile on torch >= 2.8 (ops.py:20-42): Dynamo traces through its forward into our custom op."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=41)
+    x = torch.randn(8, 512, device=dev, dtype=torch.float16)
+    with H.Installed(pkg, mods):
+        want = lin(x)
+        try:
+            fn = torch.compile(lambda t: lin(t), backend="eager")
+            got = fn(x)
+        except Exception as e:                                  # noqa: BLE001 -- Dynamo's support for this subclass is the reference's business
+            pytest.skip(f"torch.compile cannot trace the reference's GGMLTensor on this torch: {type(e).__name__}")
+    assert torch.equal(got, want)

@@ -287,6 +287,55 @@ def test_dense_cache_bookkeeping(pkg):
     assert cache.bytes <= cache.budget                                                 # larger than the whole budget: not kept
     cache.clear()
     assert cache.stats()["entries"] == 0 and cache.bytes == 0
+    # low-VRAM mode: every call brings a NEW tensor object (GGMLTensor.to per forward, ops.py:57-62,209) -- nothing can ever hit.
+    # After EPHEMERAL_STREAK entries that died unused the cache stands aside and only probes now and then.
+    R = pkg.resident
+    for i in range(R.EPHEMERAL_STREAK + 40):
+        t = mk()
+        cache(t, torch.float16)
+        del t
+    st = cache.stats()
+    assert st["entries"] == 0 and st["ephemeral_bypassed"] == 40 - 40 // R.PROBE_EVERY
+    keep = mk()                                                                        # a resident tensor shows up: the next probe caches it,
+    for i in range(2 * R.PROBE_EVERY):
+        cache(keep, torch.float16)
+    assert cache.stats()["entries"] == 1 and cache.stats()["hits"] > st["hits"]        # ... its hits end the streak
+    n = cache.stats()["ephemeral_bypassed"]
+    other = mk()
+    cache(other, torch.float16)
+    assert cache.stats()["entries"] == 2 and cache.stats()["ephemeral_bypassed"] == n
+
+
+@pytest.mark.skipif(not reference.available(), reason="reference sources neither live nor staged")
+def test_reference_harness_dry_run_on_cpu(pkg, monkeypatch):
+    """tests/ref_harness.py builds the reference's real layers for tests/test_gpu_reference.py; here the same builders run with
+    device = cpu (install() falls through to the reference, so equality is trivial) -- a dry run of the harness, and a check of
+    its oracle bridge against the reference's CPU results."""
+    import ref_harness as H
+    mods = reference.load_reference_package("ggq_refdry", setitem=monkeypatch.setitem)
+    rd, ro, Q = mods["dequant"], mods["ops"], pkg.qtypes.Q
+    assert reference.source() in ("live", "staged")
+    packed = pkg.synth.make_tensor_bytes(Q.Q4_K, (6, 768), seed=11, mode="adversarial")
+    w = H.ggml(ro, packed, Q.Q4_K, (6, 768), "cpu", rows=6)
+    for dd in H.DEQUANT_DTYPES:
+        for dtype in H.DTYPES:
+            assert H.same_bits(rd.dequantize_tensor(w, dtype, dd), H.oracle_tensor(Q.Q4_K, packed, dtype, dd, (6, 768))), (dd, dtype)
+    lin, packed = H.make_linear(ro, pkg, Q.Q6_K, 24, 512, "cpu", seed=21, patches=H.lora_patch((24, 512), seed=5), dequant_dtype="target")
+    plain, _ = H.make_linear(ro, pkg, Q.Q6_K, 24, 512, "cpu", seed=21, dequant_dtype="target")
+    x = torch.randn(3, 512)
+    want = lin(x)
+    assert not torch.equal(want, plain(x))                              # the fake calculate_weight really patches
+    wref = H.oracle_tensor(Q.Q6_K, packed, torch.float32, "target", (24, 512))
+    assert torch.equal(plain(x), torch.nn.functional.linear(x, wref, torch.Tensor(plain.bias)))
+    emb, _ = H.make_embedding(ro, pkg, Q.Q8_0, 40, 512, "cpu", seed=13)
+    conv, _ = H.make_conv2d(ro, pkg, Q.Q5_0, 16, 8, 4, 4, "cpu", seed=17)
+    ids, img = torch.tensor([[0, 39, 7]]), torch.randn(2, 8, 12, 12)
+    e0, c0 = emb(ids, out_dtype=torch.float32), conv(img)
+    for options in ({}, {"dense_cache_gb": 1}, {"fused_small_m": True}, {"gather_embedding": True}):
+        with H.Installed(pkg, mods, **options):
+            assert torch.equal(lin(x), want) and torch.equal(emb(ids, out_dtype=torch.float32), e0) and torch.equal(conv(img), c0)
+    moved = plain.to("cpu")
+    assert type(moved.weight) is ro.GGMLTensor and tuple(moved.weight.shape) == (24, 512)
 
 
 def test_partition_covers_and_balances(pkg):
@@ -322,47 +371,9 @@ def test_manifests_are_well_formed(pkg):
 # ---------------------------------------------------------------- install() in front of the reference
 
 def _fake_comfy():
-    """The comfy symbols reference ops.py touches."""
-    comfy = types.ModuleType("comfy")
-    ops = types.ModuleType("comfy.ops")
-
-    class CastWeightBiasOp:
-        comfy_cast_weights = False
-
-    class manual_cast:
-        class Linear(torch.nn.Linear, CastWeightBiasOp):
-            def forward_comfy_cast_weights(self, x):
-                return torch.nn.functional.linear(x, self.weight.to(x.dtype), self.bias)
-
-            def forward(self, *a, **k):
-                return self.forward_comfy_cast_weights(*a, **k)
-
-        class Conv2d(torch.nn.Conv2d, CastWeightBiasOp):
-            pass
-
-        class Embedding(torch.nn.Embedding, CastWeightBiasOp):
-            bias = None                                    # as comfy.ops.disable_weight_init.Embedding
-
-            def forward_comfy_cast_weights(self, input, out_dtype=None):
-                return torch.nn.functional.embedding(input, self.weight.to(out_dtype), self.padding_idx)
-
-            def forward(self, *a, **k):
-                return self.forward_comfy_cast_weights(*a, **k)
-
-        class LayerNorm(torch.nn.LayerNorm, CastWeightBiasOp):
-            pass
-
-        class GroupNorm(torch.nn.GroupNorm, CastWeightBiasOp):
-            pass
-
-    ops.manual_cast = manual_cast
-    ops.cast_to = lambda t, dtype, device, non_blocking=False, copy=False: t.to(device=device, dtype=dtype)
-    mm = types.ModuleType("comfy.model_management")
-    mm.device_supports_non_blocking = lambda device: False
-    lora = types.ModuleType("comfy.lora")
-    lora.calculate_weight = lambda patches, weight, key, *a: weight
-    comfy.ops, comfy.model_management, comfy.lora = ops, mm, lora
-    return {"comfy": comfy, "comfy.ops": ops, "comfy.model_management": mm, "comfy.lora": lora}
+    """The comfy symbols reference ops.py touches: oracle/fake_comfy.py, shared with the GPU tests."""
+    from oracle import fake_comfy
+    return fake_comfy.build()
 
 
 @pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
