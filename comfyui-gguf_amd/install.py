@@ -24,6 +24,11 @@ reference's method.  Opt-in because the result matches F.linear up to fp32 summa
 unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense table (a 152 k x 3584 vocabulary is 1.1 GB).
 Tables the kernel does not take (CPU, F16 / F32 storage, ``max_norm`` set, LoRA patches) keep the
 reference's method.
+
+``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
+overlap.LayerPrefetcher: the NEXT layer's packed bytes are copied (low-VRAM mode) and unpacked on a side stream while the current
+layer's GEMM runs.  Bit-identical values; opt-in because the dense weight handed out is a view into a scratch buffer that is
+reused two layers later (see overlap.py).
 """
 import os
 
@@ -34,7 +39,7 @@ from . import dequant as _hip
 _installed = {}
 
 
-def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None):
+def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -89,7 +94,16 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         if ref_ops is None:
             raise ValueError("gather_embedding patches GGMLOps.Embedding: pass ref_ops")
         patched.append(_gather_embedding(ref_ops.GGMLOps.Embedding, unsupported))
-    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache}
+    if overlap is None:
+        overlap = os.environ.get("GGQ_OVERLAP", "0") not in ("", "0")
+    prefetcher = None
+    if overlap:
+        if ref_ops is None:
+            raise ValueError("overlap patches GGMLLayer.cast_bias_weight: pass ref_ops")
+        from .overlap import attach
+        record, prefetcher = attach(ref_ops.GGMLLayer)
+        patched.append(record)
+    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher}
     return orig
 
 
@@ -140,6 +154,12 @@ def dense_cache(ref_dequant):
     return rec["cache"] if rec else None
 
 
+def prefetcher(ref_dequant):
+    """The LayerPrefetcher of an installation (None when ``overlap`` is off): ``.stats()``."""
+    rec = _installed.get(id(ref_dequant))
+    return rec.get("prefetcher") if rec else None
+
+
 def uninstall(ref_dequant):
     rec = _installed.pop(id(ref_dequant), None)
     if rec:
@@ -147,3 +167,5 @@ def uninstall(ref_dequant):
             setattr(mod, name, fn)
         if rec.get("cache") is not None:
             rec["cache"].clear()
+        if rec.get("prefetcher") is not None:
+            rec["prefetcher"].close()

@@ -1,0 +1,280 @@
+"""Opt-in: unpack layer i+1 while layer i computes -- and, in low-VRAM mode, move its packed bytes host->device meanwhile.
+
+The reference's ``GGMLLayer.cast_bias_weight`` (ops.py:194-211) does, per layer and per forward, on ONE stream:
+
+    weight = s.weight.to(device)          # low-VRAM mode: a PCIe copy of the packed bytes (ops.py:209)
+    weight = dequantize_tensor(weight)    # HBM-bound unpack (ops.py:177)
+    F.linear(input, weight, bias)         # MFMA-bound GEMM (ops.py:244)
+
+Three different resources, used strictly one after the other.  ``LayerPrefetcher`` learns the order in which layers are called
+(module A is followed by module B -- it repeats every denoising step) and, when A is called, enqueues B's copy + unpack on a
+SIDE stream into one of two persistent scratch buffers (include/ggq.h ``ggq_overlap_*``: event-ordered after everything the main
+stream holds, so the buffer's previous consumer is done).  When B is called its dense weight is already there (or on its way: the
+main stream waits on the event, never the host).  The values are the very same kernels' output: results stay bit-identical.
+
+What it changes for the caller, and why it is opt-in (``install(..., overlap=True)`` / ``GGQ_OVERLAP=1``):
+  * the dense weight handed to ``F.linear`` is a view into a scratch buffer that is rewritten two layers later.  The reference's
+    layers consume the weight immediately (ops.py:242-271), so nothing notices -- but code that stashes the result of
+    ``cast_bias_weight`` would;
+  * low-VRAM mode keeps a PINNED host copy of every packed weight it has seen (the async copy needs page-locked memory): host RAM
+    of the size of the packed model (6.8 GB for FLUX.1-dev Q4_K_M);
+  * 2 x the largest dense weight of scratch per device (2 x 132 MB for FLUX.1-dev in bf16).
+LoRA-patched weights (patched in place, ops.py:183-190), non-quantized weights, dtypes the kernels do not emit, tracing under
+torch.compile and stream capture all take the reference's path untouched; a mispredicted order only costs the prefetch.
+"""
+import ctypes
+import sys
+import threading
+import weakref
+
+import torch
+
+from . import _native
+from . import dequant as _dq
+
+N_SLOTS = 2
+
+
+class _Slot:
+    __slots__ = ("dense", "packed", "owner")
+
+    def __init__(self):
+        self.dense = None         # uint8 scratch on the device, grown to the largest dense weight seen
+        self.packed = None        # uint8 staging for packed bytes copied from the host (low-VRAM mode)
+        self.owner = None         # id(module) whose prefetched weight currently lives here
+
+
+class _Device:
+    def __init__(self, index):
+        self.index = index
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(index):
+            _native.check(_native.lib().ggq_overlap_create(N_SLOTS, ctypes.byref(self.handle)), "ggq_overlap_create")
+        self.slots = [_Slot() for _ in range(N_SLOTS)]
+        self.turn = 0
+
+    def close(self):
+        if self.handle:
+            _native.lib().ggq_overlap_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+class LayerPrefetcher:
+    """``weight = prefetcher.weight_for(module, dtype, device)`` returns what ``module.get_weight(module.weight.to(device), dtype)``
+    returns (same values), from the side stream's buffer when the call was predicted, else computed on the spot; either way it
+    then schedules the predicted NEXT module's weight.  One instance serves one thread of forward calls (ComfyUI runs a model on
+    one thread); calls from other threads take the reference's path."""
+
+    def __init__(self):
+        self._devices = {}
+        self._next = {}            # id(module) -> weakref to the module that was called after it last time
+        self._last = {}            # id(module) -> (dtype, device index, dequant_dtype) of its last call
+        self._pinned = {}          # id(module) -> (weakref to the CPU weight object, version, pinned uint8 copy)
+        self._pending = {}         # id(module) -> (weight object ref, version, dtype, compute dtype, device index, slot index, dense view)
+        self._prev = None          # weakref to the module of the previous call
+        self._owner_thread = None
+        self.hits = self.misses = self.mispredicted = self.bypassed = 0
+
+    # ---- what qualifies
+    def eligible(self, module, dtype, device):
+        w = getattr(module, "weight", None)
+        if w is None or getattr(w, "patches", None) or dtype not in _dq._OUT_CODE:
+            return False
+        qtype = getattr(w, "tensor_type", None)
+        if qtype not in _dq._HIP_TABLE and _dq._qtype_key(qtype) not in _dq._HIP_TABLE:
+            return False
+        if device is None or torch.device(device).type != "cuda":
+            return False
+        tid = threading.get_ident()
+        if self._owner_thread is None:
+            self._owner_thread = tid
+        if tid != self._owner_thread or _dq._is_compiling():
+            return False
+        index = torch.device(device).index
+        index = torch.cuda.current_device() if index is None else index
+        return bool(_dq._DEVICE_OK.get(index) or _dq._device_served(index))
+
+    def break_chain(self):
+        self._prev = None
+        self.bypassed += 1
+
+    # ---- internals
+    def _dev(self, index):
+        d = self._devices.get(index)
+        if d is None:
+            d = self._devices[index] = _Device(index)
+        return d
+
+    @staticmethod
+    def _compute_dtype(module, dtype):
+        dd = getattr(module, "dequant_dtype", None)
+        return dtype if dd == "target" else dd
+
+    def _host_bytes(self, module, w):
+        """Pinned copy of a CPU-resident packed weight (made once per weight object and version)."""
+        ent = self._pinned.get(id(module))
+        if ent is not None and ent[0]() is w and ent[1] == w._version:
+            return ent[2]
+        with _dq._NoTorchFunction():
+            flat = _dq._as_bytes(w, align=False)
+            pinned = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
+            pinned.copy_(flat)
+        self._pinned[id(module)] = (weakref.ref(w), w._version, pinned)
+        return pinned
+
+    def _schedule(self, module, dtype, index, main_stream):
+        """Enqueue module's (copy +) unpack on the side stream of device `index`.  Returns False if it cannot be prefetched."""
+        w = module.weight
+        qtype = getattr(w, "tensor_type", None)
+        ent = _dq._HIP_TABLE.get(qtype) or _dq._HIP_TABLE.get(_dq._qtype_key(qtype))
+        if ent is None or getattr(w, "patches", None):
+            return False
+        compute = self._compute_dtype(module, dtype)
+        try:
+            compute_code = _dq._check_compute(compute)
+        except _dq.GGQUnsupported:
+            return False
+        qid, block_size, type_size = ent
+        dev = self._dev(index)
+        slot_index = dev.turn
+        slot = dev.slots[slot_index]
+        with _dq._NoTorchFunction():
+            on_host = not w.is_cuda
+            if on_host:
+                host = self._host_bytes(module, w)
+                nbytes = host.numel()
+            else:
+                if w.device.index != index:
+                    return False
+                data = w
+                if data.dtype is not torch.uint8 or not data.is_contiguous() or data.data_ptr() & 15:
+                    return False                          # views / misaligned starts: the ordinary path copies them first
+                nbytes = data.numel()
+            n_blocks = nbytes // type_size
+            shape = tuple(getattr(w, "tensor_shape", ()))
+            n = n_blocks * block_size
+            numel = 1
+            for s in shape:
+                numel *= int(s)
+            if numel != n or n == 0:
+                return False
+            dense_bytes = n * (4 if dtype is torch.float32 else 2)
+            if slot.dense is None or slot.dense.numel() < dense_bytes or (on_host and (slot.packed is None or slot.packed.numel() < nbytes)):
+                # growing a buffer frees the old one: nothing on either stream may still be using it
+                torch.cuda.synchronize(index)
+                with torch.cuda.device(index):
+                    if slot.dense is None or slot.dense.numel() < dense_bytes:
+                        slot.dense = torch.empty(dense_bytes, dtype=torch.uint8, device=f"cuda:{index}")
+                    if on_host and (slot.packed is None or slot.packed.numel() < nbytes):
+                        slot.packed = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{index}")
+            dense = slot.dense[:dense_bytes].view(dtype).view(shape)
+            if slot.owner is not None:
+                self._pending.pop(slot.owner, None)       # whatever lived in this slot is about to be overwritten
+            if _dq._cur_device() != index:
+                with torch.cuda.device(index):
+                    rc = self._prefetch_call(dev, slot_index, qid, host if on_host else None, slot.packed if on_host else data, nbytes, n_blocks,
+                                             dense, compute_code, dtype, main_stream)
+            else:
+                rc = self._prefetch_call(dev, slot_index, qid, host if on_host else None, slot.packed if on_host else data, nbytes, n_blocks,
+                                         dense, compute_code, dtype, main_stream)
+        _native.check(rc, "ggq_overlap_prefetch")
+        slot.owner = id(module)
+        dev.turn = (slot_index + 1) % N_SLOTS
+        self._pending[id(module)] = (weakref.ref(w), w._version, dtype, compute, index, slot_index, dense)
+        return True
+
+    @staticmethod
+    def _prefetch_call(dev, slot_index, qid, host, dev_packed, nbytes, n_blocks, dense, compute_code, dtype, main_stream):
+        return _native.lib().ggq_overlap_prefetch(dev.handle, slot_index, qid, None if host is None else host.data_ptr(), dev_packed.data_ptr(), nbytes,
+                                                  n_blocks, dense.data_ptr(), compute_code, _dq._OUT_CODE[dtype], main_stream)
+
+    # ---- the call
+    def weight_for(self, module, dtype, device, compute_now):
+        """``compute_now()`` produces the weight the reference's way (used on a miss).  Call only when ``eligible()``."""
+        index = torch.device(device).index
+        index = _dq._cur_device() if index is None else index
+        main_stream = _dq._raw_stream(index)
+        key = id(module)
+        w = module.weight
+        pend = self._pending.pop(key, None)
+        dense = None
+        if pend is not None:
+            wref, version, p_dtype, p_compute, p_index, slot_index, p_dense = pend
+            dev = self._devices[p_index]
+            if (wref() is w and version == w._version and p_dtype is dtype and p_index == index and p_compute == self._compute_dtype(module, dtype)):
+                _native.check(_native.lib().ggq_overlap_wait(dev.handle, slot_index, main_stream), "ggq_overlap_wait")
+                dense = p_dense
+                self.hits += 1
+            else:
+                self.mispredicted += 1
+            if dev.slots[slot_index].owner == key:
+                dev.slots[slot_index].owner = None
+        if dense is None:
+            dense = compute_now()
+            self.misses += 1
+        # learn the order, then look one layer ahead
+        prev = self._prev() if self._prev is not None else None
+        if prev is not None:
+            self._next[id(prev)] = weakref.ref(module)
+        self._prev = weakref.ref(module)
+        self._last[key] = (dtype, index)
+        nref = self._next.get(key)
+        nxt = nref() if nref is not None else None
+        if nxt is not None and id(nxt) not in self._pending:
+            last = self._last.get(id(nxt))
+            if last is not None and last[1] == index:
+                self._schedule(nxt, last[0], index, main_stream)
+        return dense
+
+    def stats(self):
+        return {"hits": self.hits, "misses": self.misses, "mispredicted": self.mispredicted, "bypassed": self.bypassed,
+                "pinned_host_bytes": sum(e[2].numel() for e in self._pinned.values()),
+                "scratch_bytes": sum((s.dense.numel() if s.dense is not None else 0) + (s.packed.numel() if s.packed is not None else 0)
+                                     for d in self._devices.values() for s in d.slots)}
+
+    def close(self):
+        for index in list(self._devices):
+            torch.cuda.synchronize(index)
+        for d in self._devices.values():
+            d.close()
+        self._devices.clear()
+        self._pending.clear()
+        self._pinned.clear()
+        self._next.clear()
+        self._last.clear()
+        self._prev = None
+
+
+def attach(layer_cls, prefetcher=None):
+    """Wrap ``layer_cls.cast_bias_weight`` (the reference's ``GGMLLayer``, ops.py:194-211, or this package's stand-in).
+    Returns ((owner, name, original) for uninstall, the prefetcher)."""
+    pf = prefetcher or LayerPrefetcher()
+    original = layer_cls.cast_bias_weight
+    ops_module = sys.modules.get(layer_cls.__module__)
+    comfy = getattr(ops_module, "comfy", None)            # the reference's `import comfy.ops` / `comfy.model_management`
+
+    def cast_bias_weight(s, input=None, dtype=None, device=None, bias_dtype=None):
+        if input is not None:                              # ops.py:195-201, verbatim semantics
+            if dtype is None:
+                dtype = getattr(input, "dtype", torch.float32)
+            if bias_dtype is None:
+                bias_dtype = dtype
+            if device is None:
+                device = input.device
+        if not pf.eligible(s, dtype, device):
+            pf.break_chain()
+            return original(s, input, dtype, device, bias_dtype)
+        bias = None
+        if comfy is not None:
+            non_blocking = comfy.model_management.device_supports_non_blocking(device)
+            if s.bias is not None:
+                bias = s.get_weight(s.bias.to(device), dtype)
+                bias = comfy.ops.cast_to(bias, bias_dtype, device, non_blocking=non_blocking, copy=False)
+        elif s.bias is not None:
+            bias = s.get_weight(s.bias.to(device), dtype).to(device=device, dtype=bias_dtype)
+        weight = pf.weight_for(s, dtype, device, lambda: s.get_weight(s.weight.to(device), dtype).to(device=device, dtype=dtype))
+        return weight, bias
+
+    cast_bias_weight.__wrapped__ = original
+    layer_cls.cast_bias_weight = cast_bias_weight
+    return (layer_cls, "cast_bias_weight", original), pf

@@ -132,6 +132,26 @@ uint32_t ggq_plan_kernels(const ggq_plan* plan);
 
 void ggq_plan_destroy(ggq_plan* plan);
 
+/* ---- layer i+1 while layer i computes (side-stream prefetch) --------------------------------------------------------------- */
+
+/* The reference dequantizes a layer's weight and then runs its GEMM, one after the other on one stream (ops.py:242-244), and in
+ * low-VRAM mode first copies the packed bytes host->device on that same stream (ops.py:209).  The unpack is HBM-bound, the copy
+ * PCIe-bound, the GEMM MFMA-bound: a ggq_overlap owns a side stream (and per-slot events) on which the NEXT layer's copy + unpack
+ * run while the current layer's GEMM occupies the matrix cores.  Values are the same kernels' output: bit-identical.
+ *   ggq_overlap_create     side stream + 2 events per slot on the current device; n_slots in [1, 16].
+ *   ggq_overlap_prefetch   enqueue on the side stream, ordered after everything `main_stream` holds at this moment (so a slot's
+ *                          previous consumer has finished): [if host_packed != NULL: copy packed_bytes host_packed -> dev_packed]
+ *                          then ggq_dequant(qtype, dev_packed, n_blocks, out, compute_dtype, out_dtype).  host_packed should be
+ *                          pinned memory (a pageable source makes the copy synchronous for the calling thread).
+ *   ggq_overlap_wait       make `main_stream` wait for the slot's last prefetch (no host sync).
+ * The caller owns every buffer and keeps it alive until the consumer has run; one thread drives a ggq_overlap at a time. */
+typedef struct ggq_overlap ggq_overlap;
+int ggq_overlap_create(int n_slots, ggq_overlap** out);
+int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int qtype, const void* host_packed, void* dev_packed, uint64_t packed_bytes,
+                         uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* main_stream);
+int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream);
+void ggq_overlap_destroy(ggq_overlap* ov);
+
 /* ---- fused dequantize + linear for a few rows of x (opt-in) ------------------------- */
 
 /* y[m, rows] = x[m, cols] @ W^T (+ bias[rows]), W = dequantize_tensor(packed, dtype) of logical shape (rows, cols), 1 <= m <= 4,

@@ -1,0 +1,155 @@
+"""overlap.LayerPrefetcher: the next layer's (host->device copy and) unpack on a side stream under the current layer's GEMM.
+Bit-identical to the plain path in every situation the prefetch can be in: predicted, mispredicted, stale, bypassed."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _layers(pkg, specs, wdev, seed=0, dequant_dtype=None):
+    out = []
+    for i, (qname, rows, cols, bias) in enumerate(specs):
+        q = pkg.qtypes.Q[qname]
+        packed = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=seed + i, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(packed.copy()).to(wdev), tensor_type=q, tensor_shape=(rows, cols))
+        b = None
+        if bias:
+            b = pkg.ops.GGMLTensor(torch.randn(rows, generator=torch.Generator().manual_seed(seed + 100 + i)).to(wdev), tensor_type=pkg.qtypes.Q.F32, tensor_shape=(rows,))
+        lin = pkg.ops.GGMLLinear(w, b)
+        lin.dequant_dtype = dequant_dtype
+        out.append((lin, packed, q))
+    return out
+
+
+SPECS = [("Q4_K", 512, 1024, True), ("Q5_K", 1536, 512, False), ("Q8_0", 256, 1024, True), ("Q6_K", 768, 768, False),
+         ("Q4_0", 1024, 512, True), ("IQ4_XS", 512, 2048, False), ("Q2_K", 2048, 256, True)]
+
+
+@pytest.fixture
+def attached(pkg):
+    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer)
+    yield pf
+    setattr(*record)
+    pf.close()
+
+
+def _inputs(layers, m, dtype):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    return [torch.randn(m, lin.weight.shape[1], device=DEV, dtype=dtype, generator=g) for lin, _, _ in layers]
+
+
+@pytest.mark.parametrize("wdev", ["cuda:0", "cpu"], ids=["resident", "lowvram"])
+@pytest.mark.parametrize("dtype,dd", [(torch.bfloat16, None), (torch.float16, "target"), (torch.float32, torch.bfloat16)])
+def test_chain_is_bit_identical_and_predicted(pkg, wdev, dtype, dd):
+    layers = _layers(pkg, SPECS, wdev, seed=10, dequant_dtype=dd)
+    xs = _inputs(layers, 33, dtype)
+    want = [lin(x) for (lin, _, _), x in zip(layers, xs)]
+    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer)
+    try:
+        for p in range(4):
+            got = [lin(x) for (lin, _, _), x in zip(layers, xs)]
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+        st = pf.stats()
+        # pass 1 learns the order (all misses); the wrap-around last -> first is learnt at the start of pass 2 (one more miss)
+        assert st["misses"] == len(layers) + 1 and st["hits"] == 3 * len(layers) - 1 and st["mispredicted"] == 0
+        assert (st["pinned_host_bytes"] > 0) == (wdev == "cpu")
+        # the weight itself, against the oracle (the scratch view handed to F.linear)
+        lin, packed, q = layers[0]
+        w, _ = lin.cast_bias_weight(xs[0])
+        kind = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}
+        compute = dtype if dd == "target" else dd
+        ref = oracle.dequant_tensor(q, packed, "f16" if compute is None else kind[compute], kind[dtype])
+        bits = w.cpu().contiguous().view(torch.int32 if dtype is torch.float32 else torch.int16).numpy().reshape(-1)
+        assert np.array_equal(bits, np.ascontiguousarray(ref).view(bits.dtype).reshape(-1))
+    finally:
+        setattr(*record)
+        pf.close()
+
+
+def test_overlap_under_long_gemms_reuses_slots_safely(pkg, attached):
+    """FLUX-sized layers with 4608-token inputs: the GEMMs are long, the side stream really runs ahead, and every scratch slot is
+    rewritten while earlier GEMMs are still in flight -- the event ordering has to hold."""
+    specs = [("Q4_K", 3072, 3072, False), ("Q5_K", 9216, 3072, False), ("Q4_K", 3072, 12288, False), ("Q4_K", 12288, 3072, False)] * 2
+    layers = _layers(pkg, specs, "cuda:0", seed=40)
+    xs = [torch.randn(4608, lin.weight.shape[1], device=DEV, dtype=torch.bfloat16) * 0.05 for lin, _, _ in layers]
+    record = (pkg.ops.GGMLLayer, "cast_bias_weight", pkg.ops.GGMLLayer.cast_bias_weight)
+    setattr(pkg.ops.GGMLLayer, "cast_bias_weight", pkg.ops.GGMLLayer.cast_bias_weight.__wrapped__)      # plain path first
+    want = [lin(x) for (lin, _, _), x in zip(layers, xs)]
+    setattr(*record)
+    for p in range(3):
+        got = [lin(x) for (lin, _, _), x in zip(layers, xs)]
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert attached.stats()["hits"] == 2 * len(layers) - 1
+
+
+@pytest.mark.parametrize("wdev", ["cuda:0", "cpu"], ids=["resident", "lowvram"])
+def test_stale_mispredicted_and_bypassed(pkg, attached, wdev):
+    layers = _layers(pkg, SPECS[:5], wdev, seed=70)
+    xs = _inputs(layers, 9, torch.bfloat16)
+    plain = pkg.ops.GGMLLayer.cast_bias_weight.__wrapped__
+
+    def reference(i):
+        lin, x = layers[i][0], xs[i]
+        w, b = plain(lin, x)
+        return torch.nn.functional.linear(x, w, b)
+
+    for _ in range(2):
+        for i in range(5):
+            assert torch.equal(layers[i][0](xs[i]), reference(i))
+    # (1) the packed bytes of the NEXT predicted layer (layer 0, already prefetched) change in place: the prefetch is stale
+    with torch.no_grad():
+        torch.Tensor.add_(layers[0][0].weight.as_subclass(torch.Tensor)[64:80], 1)
+    before = attached.stats()["mispredicted"]
+    assert torch.equal(layers[0][0](xs[0]), reference(0))
+    assert attached.stats()["mispredicted"] == before + 1
+    # (2) a different order: 0 -> 3 -> 1 (layer 1 was prefetched after 0; 3 is called instead)
+    for i in (3, 1, 4, 2, 0, 3, 1):
+        assert torch.equal(layers[i][0](xs[i]), reference(i))
+    # (3) a LoRA-patched layer in the chain takes the plain path (its weight is patched in place), the chain goes on
+    layers[2][0].weight.patches = [("patch", "key")]
+    n = attached.stats()["bypassed"]
+    for _ in range(2):
+        for i in range(5):
+            assert torch.equal(layers[i][0](xs[i]), reference(i))
+    assert attached.stats()["bypassed"] == n + 2
+    layers[2][0].weight.patches = []
+    # (4) another dtype than last time for the same layers
+    xs16 = [x.to(torch.float16) for x in xs]
+    for _ in range(2):
+        for i in range(5):
+            lin = layers[i][0]
+            w, b = plain(lin, xs16[i])
+            assert torch.equal(lin(xs16[i]), torch.nn.functional.linear(xs16[i], w, b))
+
+
+def test_c_abi_argument_checks(pkg):
+    import ctypes
+    nat = pkg._native
+    lib = nat.lib()
+    h = ctypes.c_void_p()
+    assert lib.ggq_overlap_create(0, ctypes.byref(h)) == nat.GGQ_ERR_ARG and lib.ggq_overlap_create(17, ctypes.byref(h)) == nat.GGQ_ERR_ARG
+    assert lib.ggq_overlap_create(2, ctypes.byref(h)) == nat.GGQ_OK and h.value
+    q4k = int(pkg.qtypes.Q.Q4_K)
+    assert lib.ggq_overlap_prefetch(h, 2, q4k, None, 16, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG       # slot out of range
+    assert lib.ggq_overlap_prefetch(h, 0, 99, None, 16, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_QTYPE
+    assert lib.ggq_overlap_prefetch(h, 0, q4k, None, 24, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_ALIGN
+    assert lib.ggq_overlap_prefetch(h, 0, q4k, 4096, 16, 100, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG    # host copy shorter than the blocks
+    assert lib.ggq_overlap_wait(h, 5, None) == nat.GGQ_ERR_ARG and lib.ggq_overlap_wait(None, 0, None) == nat.GGQ_ERR_ARG
+    # a real round trip through the raw entry points: prefetch on the side stream, wait on the main one, compare with the oracle
+    q = pkg.qtypes.Q.Q4_K
+    blocks = pkg.synth.make_blocks(q, 100, seed=3)
+    d = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    out = torch.empty(100 * 256, dtype=torch.float16, device=DEV)
+    s = torch.cuda.current_stream(DEV).cuda_stream
+    assert lib.ggq_overlap_prefetch(h, 1, q4k, None, d.data_ptr(), d.numel(), 100, out.data_ptr(), 0, 0, s) == nat.GGQ_OK
+    assert lib.ggq_overlap_wait(h, 1, s) == nat.GGQ_OK
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), oracle.dequant_f16(q, blocks).view(np.uint16))
+    lib.ggq_overlap_destroy(h)

@@ -147,6 +147,31 @@ def test_reference_linear_with_dense_cache(mods, pkg, dev, monkeypatch, resident
         assert st["ephemeral_bypassed"] > 0                      # detected: per-forward copies are not worth caching
 
 
+@pytest.mark.parametrize("resident", [True, False], ids=["weights-on-gpu", "lowvram-cpu-weights"])
+def test_reference_layers_with_overlap(mods, pkg, dev, resident):
+    """install(overlap=True): the reference's GGMLLayer.cast_bias_weight wrapped by the side-stream prefetcher -- a chain of the
+    reference's Linear layers (one of them LoRA-patched, one with dequant_dtype "target") gives the same outputs pass after pass,
+    and from the second pass on the weights come from the prefetch."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    wdev = dev if resident else "cpu"
+    chain = [H.make_linear(ro, pkg, Q.Q4_K, 96, 512, wdev, seed=1)[0], H.make_linear(ro, pkg, Q.Q6_K, 40, 768, wdev, seed=2, bias=False)[0],
+             H.make_linear(ro, pkg, Q.Q5_0, 64, 512, wdev, seed=3, patches=H.lora_patch((64, 512), seed=4))[0],
+             H.make_linear(ro, pkg, Q.Q8_0, 48, 1024, wdev, seed=5, dequant_dtype="target")[0], H.make_linear(ro, pkg, Q.IQ4_NL, 32, 512, wdev, seed=6)[0]]
+    xs = [torch.randn(17, lin.in_features, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(i)) for i, lin in enumerate(chain)]
+    want = [lin(x) for lin, x in zip(chain, xs)]
+    with H.Installed(pkg, mods, overlap=True):
+        pf = pkg.install.prefetcher(mods["dequant"])
+        for _ in range(4):
+            for lin, x, w in zip(chain, xs, want):
+                got = lin(x)
+                assert type(got) is torch.Tensor and torch.equal(got, w)
+        st = pf.stats()
+    # 4 eligible layers per pass; the patched one breaks the chain, so the layer after it is never predicted, and the wrap-around
+    # (last layer -> first layer) is only learnt at the start of pass 2: hits 0 + 2 + 3 + 3, misses 4 + 2 + 1 + 1
+    assert st["bypassed"] == 4 and st["hits"] == 8 and st["misses"] == 8 and st["mispredicted"] == 0
+    assert pkg.install.prefetcher(mods["dequant"]) is None and ro.GGMLLayer.cast_bias_weight.__name__ == "cast_bias_weight"
+
+
 def test_reference_linear_fused_small_m(mods, pkg, dev, monkeypatch):
     """install(fused_small_m=True): m > 4 rows and LoRA-patched weights (weight OR bias) keep the reference's method bit for bit;
     m <= 4 goes through the fused kernel and matches to fp32-summation tolerance."""

@@ -3,12 +3,14 @@
 run the way GGMLOps.Linear.forward does (reference ops.py:242-244) -- dequantize the weight, F.linear, drop it -- for one
 denoising step's worth of tokens, against the same F.linear calls on weights dequantized once up front.
 
-    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5] [--dense-cache-gb N] [--fused-small-m]
+    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5] [--dense-cache-gb N] [--fused-small-m] [--overlap] [--lowvram]
 
 Prints one JSON line: ms per emulated step with on-the-fly dequant, with resident dense weights, and the difference
 (the cost of the dequant path per step).  Layers run back to back on one stream; img/txt token counts are not modelled
 separately (every layer sees --tokens rows), modulation layers see 1 row (they act on the conditioning vector).
---dense-cache-gb / --fused-small-m switch on the two opt-ins of install() for the quantized pass (resident.DenseCache, fused.linear_small)."""
+--dense-cache-gb / --fused-small-m / --overlap switch on the opt-ins of install() for the quantized pass (resident.DenseCache,
+fused.linear_small, overlap.LayerPrefetcher); --lowvram keeps the packed weights on the CPU (the reference's low-VRAM mode:
+``s.weight.to(device)`` per layer per forward, ops.py:209)."""
 import argparse
 import json
 import os
@@ -30,6 +32,8 @@ def main():
     ap.add_argument("--mix", default="Q4_K_M")
     ap.add_argument("--dense-cache-gb", type=float, default=0.0, help="opt-in resident.DenseCache budget (0 = off, the reference's behaviour)")
     ap.add_argument("--fused-small-m", action="store_true", help="opt-in fused dequantize + linear for the 1-row (modulation) layers")
+    ap.add_argument("--overlap", action="store_true", help="opt-in side-stream prefetch of the next layer's weight (overlap.LayerPrefetcher)")
+    ap.add_argument("--lowvram", action="store_true", help="packed weights live on the CPU and are copied per layer per forward (ops.py:209)")
     args = ap.parse_args()
     pkg = load_package()
     pkg.ops.GGMLLinear.fuse_small_m = args.fused_small_m
@@ -46,7 +50,7 @@ def main():
         for off in pkg.qtypes.SCALE_FIELDS[q]:                     # small scales: keep activations finite
             vals = (torch.rand(n_blocks, device=dev, generator=g) * 1e-3 + 1e-4).to(torch.float16)
             data[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
-        w = pkg.ops.GGMLTensor(data.reshape(-1), tensor_type=q, tensor_shape=(rows, cols))
+        w = pkg.ops.GGMLTensor(data.reshape(-1).cpu() if args.lowvram else data.reshape(-1), tensor_type=q, tensor_shape=(rows, cols))
         m = 1 if ("mod" in name) else args.tokens
         if (m, cols) not in inputs:
             inputs[(m, cols)] = torch.randn(m, cols, device=dev, dtype=dtype) * 0.05
@@ -57,11 +61,15 @@ def main():
         cache = pkg.resident.DenseCache(args.dense_cache_gb * 1e9, pkg.dequant.dequantize_tensor)
         pkg.ops.GGMLLayer._dequantize = staticmethod(cache)
 
+    prefetcher = None
+    if args.overlap:
+        _, prefetcher = pkg.overlap.attach(pkg.ops.GGMLLayer)
+
     def step_quantized():
         for lin, x in layers:
             lin(x)
 
-    dense = [pkg.dequant.dequantize_tensor(lin.weight, dtype) for lin, _ in layers]
+    dense = [pkg.dequant.dequantize_tensor(lin.weight.to(dev), dtype) for lin, _ in layers]
 
     def step_dense():
         for (lin, x), w in zip(layers, dense):
@@ -69,6 +77,7 @@ def main():
 
     def timed(fn):
         fn()
+        fn()                                                   # the prefetcher learns the layer order in the first pass
         torch.cuda.synchronize()
         ts = []
         for _ in range(args.reps):
@@ -90,6 +99,7 @@ def main():
         "best_ms": {"on_the_fly": round(q_min, 2), "dense": round(d_min, 2)},
         "gemm_TFLOPs_dense": round(flops / d_med / 1e9, 1),
         "dense_cache": cache.stats() if cache is not None else None,
+        "overlap": prefetcher.stats() if prefetcher is not None else None, "lowvram": args.lowvram,
         "dense_weight_GB": round(n_el * 2 / 1e9, 1), "packed_weight_GB": round(sum(lin.weight.numel() for lin, _ in layers) / 1e9, 2)}))
 
 
