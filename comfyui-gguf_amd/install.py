@@ -26,8 +26,9 @@ Tables the kernel does not take (CPU, F16 / F32 storage, ``max_norm`` set, LoRA 
 reference's method.
 
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
-overlap.LayerPrefetcher: the NEXT layer's packed bytes are copied (low-VRAM mode) and unpacked on a side stream while the current
-layer's GEMM runs.  Bit-identical values; opt-in because the dense weight handed out is a view into a scratch buffer that is
+overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
+and unpacked on a side stream while the current layer's GEMM runs (``overlap="all"``: also for weights already in HBM, where it
+measured slower).  Bit-identical values; opt-in because the dense weight handed out is a view into a scratch buffer that is
 reused two layers later (see overlap.py).
 """
 import os
@@ -95,13 +96,14 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
             raise ValueError("gather_embedding patches GGMLOps.Embedding: pass ref_ops")
         patched.append(_gather_embedding(ref_ops.GGMLOps.Embedding, unsupported))
     if overlap is None:
-        overlap = os.environ.get("GGQ_OVERLAP", "0") not in ("", "0")
+        overlap = os.environ.get("GGQ_OVERLAP", "0")
+        overlap = "all" if overlap == "all" else overlap not in ("", "0")
     prefetcher = None
     if overlap:
         if ref_ops is None:
             raise ValueError("overlap patches GGMLLayer.cast_bias_weight: pass ref_ops")
         from .overlap import attach
-        record, prefetcher = attach(ref_ops.GGMLLayer)
+        record, prefetcher = attach(ref_ops.GGMLLayer, resident=(overlap == "all"))
         patched.append(record)
     _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher}
     return orig

@@ -12,6 +12,10 @@ SIDE stream into one of two persistent scratch buffers (include/ggq.h ``ggq_over
 stream holds, so the buffer's previous consumer is done).  When B is called its dense weight is already there (or on its way: the
 main stream waits on the event, never the host).  The values are the very same kernels' output: results stay bit-identical.
 
+Measured (tools/flux_forward_emulation.py, FLUX.1-dev, 4608 tokens, bf16; profiles/r02_flux_forward_emulation_overlap.json):
+low-VRAM mode 205 -> 166 ms per step; with the packed weights already in HBM the same mechanism LOSES (74.8 -> 77.1 ms), so by
+default (``overlap=True``) only CPU-resident weights are prefetched; ``overlap="all"`` prefetches resident ones too.
+
 What it changes for the caller, and why it is opt-in (``install(..., overlap=True)`` / ``GGQ_OVERLAP=1``):
   * the dense weight handed to ``F.linear`` is a view into a scratch buffer that is rewritten two layers later.  The reference's
     layers consume the weight immediately (ops.py:242-271), so nothing notices -- but code that stashes the result of
@@ -65,7 +69,12 @@ class LayerPrefetcher:
     then schedules the predicted NEXT module's weight.  One instance serves one thread of forward calls (ComfyUI runs a model on
     one thread); calls from other threads take the reference's path."""
 
-    def __init__(self):
+    def __init__(self, resident=False):
+        # resident=False (default): only CPU-resident packed weights (low-VRAM mode) are prefetched.  For weights that already
+        # live in HBM the side stream LOSES on MI355X (emulated FLUX.1-dev step 74.8 -> 77.1 ms at 4608 tokens, 21.4 -> 23.3 ms at
+        # 512, profiles/r02_flux_forward_emulation_overlap.json): the unpack kernels are 6-18 us, a cross-queue event dependency
+        # costs about as much twice per layer, and the unpack's streaming traffic disturbs the GEMM's cache residency.
+        self.resident = bool(resident)
         self._devices = {}
         self._next = {}            # id(module) -> weakref to the module that was called after it last time
         self._last = {}            # id(module) -> (dtype, device index, dequant_dtype) of its last call
@@ -79,6 +88,8 @@ class LayerPrefetcher:
     def eligible(self, module, dtype, device):
         w = getattr(module, "weight", None)
         if w is None or getattr(w, "patches", None) or dtype not in _dq._OUT_CODE:
+            return False
+        if not self.resident and w.device.type != "cpu":
             return False
         qtype = getattr(w, "tensor_type", None)
         if qtype not in _dq._HIP_TABLE and _dq._qtype_key(qtype) not in _dq._HIP_TABLE:
@@ -122,8 +133,10 @@ class LayerPrefetcher:
         self._pinned[id(module)] = (weakref.ref(w), w._version, pinned)
         return pinned
 
-    def _schedule(self, module, dtype, index, main_stream):
-        """Enqueue module's (copy +) unpack on the side stream of device `index`.  Returns False if it cannot be prefetched."""
+    def _schedule(self, module, dtype, index, main_stream, avoid_slot=None):
+        """Enqueue module's (copy +) unpack on the side stream of device `index`.  Returns False if it cannot be prefetched.
+        ``avoid_slot``: the slot whose weight is being handed out by THIS call -- its consumer is not enqueued yet, so the
+        event recorded now would not cover it (in the learnt order the rotation never picks it; after a reordering it can)."""
         w = module.weight
         qtype = getattr(w, "tensor_type", None)
         ent = _dq._HIP_TABLE.get(qtype) or _dq._HIP_TABLE.get(_dq._qtype_key(qtype))
@@ -137,6 +150,8 @@ class LayerPrefetcher:
         qid, block_size, type_size = ent
         dev = self._dev(index)
         slot_index = dev.turn
+        if slot_index == avoid_slot:
+            slot_index = (slot_index + 1) % N_SLOTS
         slot = dev.slots[slot_index]
         with _dq._NoTorchFunction():
             on_host = not w.is_cuda
@@ -197,13 +212,13 @@ class LayerPrefetcher:
         key = id(module)
         w = module.weight
         pend = self._pending.pop(key, None)
-        dense = None
+        dense, used_slot = None, None
         if pend is not None:
             wref, version, p_dtype, p_compute, p_index, slot_index, p_dense = pend
             dev = self._devices[p_index]
             if (wref() is w and version == w._version and p_dtype is dtype and p_index == index and p_compute == self._compute_dtype(module, dtype)):
                 _native.check(_native.lib().ggq_overlap_wait(dev.handle, slot_index, main_stream), "ggq_overlap_wait")
-                dense = p_dense
+                dense, used_slot = p_dense, slot_index
                 self.hits += 1
             else:
                 self.mispredicted += 1
@@ -223,7 +238,7 @@ class LayerPrefetcher:
         if nxt is not None and id(nxt) not in self._pending:
             last = self._last.get(id(nxt))
             if last is not None and last[1] == index:
-                self._schedule(nxt, last[0], index, main_stream)
+                self._schedule(nxt, last[0], index, main_stream, avoid_slot=used_slot)
         return dense
 
     def stats(self):
@@ -245,10 +260,10 @@ class LayerPrefetcher:
         self._prev = None
 
 
-def attach(layer_cls, prefetcher=None):
+def attach(layer_cls, prefetcher=None, resident=False):
     """Wrap ``layer_cls.cast_bias_weight`` (the reference's ``GGMLLayer``, ops.py:194-211, or this package's stand-in).
     Returns ((owner, name, original) for uninstall, the prefetcher)."""
-    pf = prefetcher or LayerPrefetcher()
+    pf = prefetcher or LayerPrefetcher(resident=resident)
     original = layer_cls.cast_bias_weight
     ops_module = sys.modules.get(layer_cls.__module__)
     comfy = getattr(ops_module, "comfy", None)            # the reference's `import comfy.ops` / `comfy.model_management`

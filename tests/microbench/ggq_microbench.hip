@@ -871,6 +871,37 @@ static void formats()
 
 // A short, fixed sequence for rocprofv3 --pmc passes: streams of KNOWN size (to calibrate
 // FETCH_SIZE / WRITE_SIZE on this access pattern) followed by the shipped kernels on the bench pool.
+// Round 2: which queue is full between the kernels' 80 % and the no-arithmetic streams' 86-88 %?  The SHIPPED Q4_K and Q2_K kernels on
+// the bench pool (64 pairs, through ggq_plan_launch) next to the three no-arithmetic streams of `ceilx` at the same output size and
+// under the same XCD run mapping: pure fill, copy, and the 9:32 read:write mix.  Driven by tests/microbench/pmc3.sh.
+static void pmc3_sequence()
+{
+    for (int qi : {7, 5}) {
+        Pool P = make_pool(QTS[qi], 64);
+        std::vector<ggq_desc> descs;
+        for (auto& d : P.descs) descs.push_back(ggq_desc{QTS[qi].id, GGQ_F16, d.packed, d.out, d.n_blocks});
+        ggq_plan* plan = nullptr;
+        if (ggq_plan_create(descs.data(), (uint32_t)descs.size(), &plan)) { printf("plan_create failed\n"); continue; }
+        for (int i = 0; i < 4; i++) ggq_plan_launch(plan, nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+        ggq_plan_destroy(plan);
+        free_pool(P);
+    }
+    const uint64_t bytes = 6ull << 30;
+    ggq::u32x4 *a, *b;
+    HIP_CHECK(hipMalloc(&a, bytes)); HIP_CHECK(hipMalloc(&b, bytes));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(a), bytes / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    const uint32_t grid = (uint32_t)(bytes / 4096);
+    for (int i = 0; i < 4; i++) {
+        k_stream_x<0><<<grid, 256>>>(a, b, 5u);
+        k_stream_x<1><<<grid, 256>>>(a, b, 5u);
+        k_stream_x<2><<<grid, 256>>>(a, b, 5u);
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
+}
+
 static void pmc_sequence()
 {
     const uint64_t bytes = 1ull << 30;
@@ -1093,6 +1124,7 @@ int main(int argc, char** argv)
     if (what == "pmc") pmc_sequence();
     if (what == "skel") skeletons();
     if (what == "pmc2") pmc2_sequence();
+    if (what == "pmc3") pmc3_sequence();
     if (what == "ab") ab_all();
     if (what == "abxcd") ab_xcd_all();
     if (what == "ceilx") ceilings_x();

@@ -31,7 +31,7 @@ SPECS = [("Q4_K", 512, 1024, True), ("Q5_K", 1536, 512, False), ("Q8_0", 256, 10
 
 @pytest.fixture
 def attached(pkg):
-    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer)
+    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer, resident=True)
     yield pf
     setattr(*record)
     pf.close()
@@ -48,7 +48,7 @@ def test_chain_is_bit_identical_and_predicted(pkg, wdev, dtype, dd):
     layers = _layers(pkg, SPECS, wdev, seed=10, dequant_dtype=dd)
     xs = _inputs(layers, 33, dtype)
     want = [lin(x) for (lin, _, _), x in zip(layers, xs)]
-    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer)
+    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer, resident=True)
     try:
         for p in range(4):
             got = [lin(x) for (lin, _, _), x in zip(layers, xs)]
@@ -127,6 +127,23 @@ def test_stale_mispredicted_and_bypassed(pkg, attached, wdev):
             lin = layers[i][0]
             w, b = plain(lin, xs16[i])
             assert torch.equal(lin(xs16[i]), torch.nn.functional.linear(xs16[i], w, b))
+
+
+def test_default_leaves_resident_weights_alone(pkg):
+    """overlap=True prefetches CPU-resident weights only: for weights already in HBM the side stream measured slower."""
+    record, pf = pkg.overlap.attach(pkg.ops.GGMLLayer)
+    try:
+        res = _layers(pkg, SPECS[:3], "cuda:0", seed=5)
+        low = _layers(pkg, SPECS[:3], "cpu", seed=5)
+        xs = _inputs(res, 4, torch.bfloat16)
+        for _ in range(3):
+            for (a, _, _), (b, _, _), x in zip(res, low, xs):
+                assert torch.equal(a(x), b(x))
+        st = pf.stats()
+        assert st["bypassed"] == 9 and st["hits"] > 0 and st["pinned_host_bytes"] > 0
+    finally:
+        setattr(*record)
+        pf.close()
 
 
 def test_c_abi_argument_checks(pkg):

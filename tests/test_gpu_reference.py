@@ -159,7 +159,7 @@ def test_reference_layers_with_overlap(mods, pkg, dev, resident):
              H.make_linear(ro, pkg, Q.Q8_0, 48, 1024, wdev, seed=5, dequant_dtype="target")[0], H.make_linear(ro, pkg, Q.IQ4_NL, 32, 512, wdev, seed=6)[0]]
     xs = [torch.randn(17, lin.in_features, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(i)) for i, lin in enumerate(chain)]
     want = [lin(x) for lin, x in zip(chain, xs)]
-    with H.Installed(pkg, mods, overlap=True):
+    with H.Installed(pkg, mods, overlap="all"):
         pf = pkg.install.prefetcher(mods["dequant"])
         for _ in range(4):
             for lin, x, w in zip(chain, xs, want):

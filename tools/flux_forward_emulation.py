@@ -63,7 +63,7 @@ def main():
 
     prefetcher = None
     if args.overlap:
-        _, prefetcher = pkg.overlap.attach(pkg.ops.GGMLLayer)
+        _, prefetcher = pkg.overlap.attach(pkg.ops.GGMLLayer, resident=True)
 
     def step_quantized():
         for lin, x in layers:
