@@ -19,8 +19,8 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 # GGQ_HIP_LIB: load another build of the library (A/B measurements); default = the in-tree build
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip")]
-HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 6
+HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
+ABI_VERSION = 7
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -79,6 +79,7 @@ SYMBOLS = {
     "ggq_overlap_prefetch": (_int, [_vp, _int, _int, _vp, _vp, _u64, _u64, _vp, _int, _int, _vp]),
     "ggq_overlap_wait": (_int, [_vp, _int, _vp]),
     "ggq_overlap_destroy": (None, [_vp]),
+    "ggq_linear_mfma": (_int, [_int, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _int, _int, _vp]),
     "ggq_dequant_rows": (_int, [_int, _vp, _u64, _u32, _vp, _u64, _vp, _int, _int, _vp]),
     # include/ggq_gguf.h
     "ggq_gguf_open": (_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),

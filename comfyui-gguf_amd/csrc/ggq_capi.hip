@@ -301,7 +301,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 6; }
+int ggq_abi_version(void) { return 7; }
 
 #ifndef GGQ_BUILD_ID
 #define GGQ_BUILD_ID "unstamped"

@@ -1,5 +1,6 @@
 // ggq_linear.hip -- C ABI over ggq_linear.hpp: y = x @ dequant(W)^T + bias for m <= 4 rows of x, from the packed blocks.
 #include "ggq_linear.hpp"
+#include "ggq_mfma.hpp"
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
 
@@ -65,7 +66,49 @@ const LinEntry LINEAR[] = {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- the MFMA kernel (ggq_mfma.hpp): tile = MB*32 rows of x  x  32 output columns; MB picked from m
+typedef hipError_t (*mfma_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, uint32_t, hipStream_t);
+
+template <class F, int OUT, int MB>
+hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    const dim3 grid((rows + 31u) / 32u, (m + (uint32_t)(MB * 32) - 1u) / (uint32_t)(MB * 32));
+    hipLaunchKernelGGL((linear_mfma<F, OUT, MB>), grid, dim3(MF_WAVES * 64), 0, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
+                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
+    return hipGetLastError();
+}
+
+constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4, 8
+struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][log2 MB]
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_mfma<F, OUT, 8>}
+#define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
+const MfmaEntry MFMA[] = {
+    GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
+    GGQ_MF(FmtQ2_K), GGQ_MF(FmtQ3_K), GGQ_MF(FmtQ4_K), GGQ_MF(FmtQ5_K), GGQ_MF(FmtQ6_K),
+    GGQ_MF(FmtIQ4_NL), GGQ_MF(FmtIQ4_XS),
+};
+
 }  // namespace
+
+extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                               void* y, int dtype, int tile_rows, void* hip_stream)
+{
+    const MfmaEntry* e = nullptr;
+    for (const MfmaEntry& c : MFMA)
+        if (c.qtype == qtype) e = &c;
+    if (!e) return GGQ_ERR_QTYPE;
+    if ((dtype != GGQ_F16 && dtype != GGQ_BF16) || cols == 0 || cols % (uint32_t)MF_SPAN != 0) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
+    if (rows == 0 || m == 0) return GGQ_OK;
+    if (!packed || !x || !y) return GGQ_ERR_ARG;
+    if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
+    // tile_rows: rows of x per workgroup tile (32, 64, 128, 256); 0 = pick from m (the smallest tile that covers m, at most 128)
+    int shape;
+    if (tile_rows == 0) shape = m <= 32 ? 0 : (m <= 64 ? 1 : 2);
+    else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
+    else return GGQ_ERR_ARG;
+    const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
+    return err == hipSuccess ? GGQ_OK : hip_fail(err);
+}
 
 extern "C" int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
                                 void* y, int dtype, void* hip_stream)

@@ -1,0 +1,177 @@
+// ggq_mfma.hpp -- gfx950 device code: y = x @ dequant(W)^T (+ bias) for MANY rows of x, straight from the packed GGUF blocks,
+// on the matrix cores -- the dense weight is never written to memory.
+//
+// Where it sits (the large-m end): GGMLOps.Linear.forward_ggml_cast_weights (reference ops.py:242-244)
+// dequantizes the whole weight (0.56 B read + 2 B written per weight for Q4_K) and hands it to F.linear (2 B read again).  Here a
+// wave decodes exactly the 8 consecutive weights it needs, in registers, into the operand of one MFMA instruction.
+//
+// Why this fits the hardware so directly: v_mfma_f32_32x32x16_{f16,bf16} wants from lane l of the B operand the 8 values
+// B[k = 8*(l/32) .. +7][j = l%32] -- eight CONSECUTIVE k of ONE column j.  With B = W^T that is eight consecutive elements of one
+// weight row: exactly one CHUNK of the dequant kernels (ggq_device.hpp), which a lane already decodes on its own from the packed
+// bytes.  So `F::fields` + `quad_f16` (+ the `.to(dtype)` rounding) produce the MFMA operand in place; no dense tile in LDS, no
+// transposes.  The A operand (x, i = row of x) has the same shape: eight consecutive k of one row, one 16-byte load per lane.
+// The contraction index may be permuted freely as long as both operands use the same permutation, so inside a 64-element span of
+// k a lane reads its four A fragments as 64 contiguous bytes.
+//
+// Shape of the work:
+//   * a workgroup owns a tile of MB*32 rows of x  x  32 rows of W (= 32 output columns); its 4 waves split K: wave w takes the
+//     256-element spans w, w+4, ... of the contraction (K % 256 == 0) and all of the tile, so every weight of the tile is
+//     decoded ONCE per workgroup; at the end the four partial accumulators are summed through LDS in a fixed order (deterministic);
+//   * per span a wave copies the span's packed bytes of its 32 weight rows (32 x 144 B for Q4_K) into its private LDS slice with
+//     16 B/lane loads -- the next span's bytes are already in flight in registers -- then runs 16 k-steps: decode one chunk
+//     (~35-45 VALU lane-ops), MB MFMAs (32 cycles each) against MB A fragments loaded straight from global memory / L2;
+//   * no __syncthreads in the main loop (waves share nothing until the reduction).
+//
+// Numerics: the WEIGHTS are the reference's values bit for bit (same decode, same fp16 op sequence, then the `.to(dtype)` of
+// dequantize_tensor); products are exact in fp32, accumulation is fp32 in the MFMA's order.  Like any GEMM against another GEMM the
+// result differs from hipBLASLt's by summation order: parity is a tolerance against an fp64 evaluation on the oracle's weights
+// (tests/test_gpu_mfma.py), hence OPT-IN.
+#pragma once
+
+#include "ggq_linear.hpp"
+
+namespace ggq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int OUT>
+GGQ_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c)
+{
+    if constexpr (OUT == OUT_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int MF_WAVES = 4;       // waves per workgroup = K-split factor
+constexpr int MF_SPAN = 256;      // contraction elements per span (one K-quant super-block, 8 legacy blocks)
+
+template <class F> struct MfmaGeom {
+    static constexpr int SPAN_BYTES = MF_SPAN / F::BS * F::TS;                     // packed bytes of one row's span
+    // a span may start at any 2-byte boundary (Q6_K 210 B, Q3_K 110 B, ...): every row keeps its own leading misalignment
+    static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0;
+    static constexpr int U = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;         // 16-byte load units per row
+    static constexpr int ROW_STRIDE = U * 16;
+    static constexpr int NUW = (32 * U + 63) / 64;                                 // load units per lane
+    static constexpr int SLICE = NUW * 64 * 16;                                    // LDS bytes per wave
+};
+
+// MB = 32-row blocks of x per workgroup tile (1, 2, 4, 8)
+template <class F, int OUT, int MB>
+__global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+                                                             const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
+                                                             uint32_t m, uint32_t n_rows, uint32_t cols)
+{
+    using G = MfmaGeom<F>;
+    static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
+    constexpr int CPB = F::BS / 8;                                                 // chunks per block
+    constexpr int RED = 16 * 64 * 4;                                               // one accumulator block of one wave, bytes
+    __shared__ __attribute__((aligned(16))) uint8_t smem[(MF_WAVES * G::SLICE > MF_WAVES * RED) ? MF_WAVES * G::SLICE : MF_WAVES * RED];
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int r = lane & 31, h = lane >> 5;
+    const uint32_t n0 = blockIdx.x * 32u, m0 = blockIdx.y * (uint32_t)(MB * 32);
+    const gcptr packed = (gcptr)packed_;
+    const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
+    const uint32_t n_spans = cols / MF_SPAN;
+    uint8_t* slice = smem + wave * G::SLICE;
+
+    // the weight row this lane decodes, and the rows of x it feeds (clamped at the edges: the stores are masked instead)
+    const uint32_t wrow = (n0 + (uint32_t)r < n_rows) ? n0 + (uint32_t)r : n_rows - 1;
+    const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
+    GGQ_GLOBAL const uint8_t* xrow[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        const uint32_t mr = m0 + (uint32_t)(mb * 32 + r);
+        xrow[mb] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
+    }
+
+    // copy of one span's packed bytes for the 32 rows: unit = (row, 16-byte piece); lane takes units lane, lane + 64, ...
+    auto fetch = [&](uint32_t span, u32x4 (&pf)[G::NUW]) {
+#pragma unroll
+        for (int u = 0; u < G::NUW; u++) {
+            const uint32_t unit = (uint32_t)(lane + 64 * u), ur = unit / (uint32_t)G::U, uu = unit % (uint32_t)G::U;
+            const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
+            const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
+            // the last unit of a row may reach past the row's span by < 16 bytes inside its aligned 16-byte unit: same page, never faults
+            pf[u] = (ur < 32u && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
+        }
+    };
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mb][i] = 0.0f;
+
+    u32x4 pf[G::NUW];
+    if ((uint32_t)wave < n_spans) fetch((uint32_t)wave, pf);
+    for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
+#pragma unroll
+        for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+        wave_sync();
+        if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);                 // the next span's bytes fly while this one is decoded
+        const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
+        const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
+        const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                              // 64 contraction elements per q
+            u32x4 xa[MB][4];
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) xa[mb][s] = *(GGQ_GLOBAL const u32x4*)(xrow[mb] + kbyte + (uint32_t)(q * 128 + s * 16));
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int j = 8 * q + 4 * h + s;                                   // chunk of the span: k = 64 q + 32 h + 8 s .. + 7
+                const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, j % CPB);
+                uint32_t w[4];
+                weights8<F, OUT>(f, w);
+                const u32x4 wb{w[0], w[1], w[2], w[3]};
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++) acc[mb] = mfma32<OUT>(xa[mb][s], wb, acc[mb]);
+            }
+        }
+        wave_sync();                                                               // the slice is rewritten at the top of the loop
+    }
+
+    // ---- sum the four K-partials through LDS, fixed order (wave 0 + 1 + 2 + 3), then bias, cast, store.
+    // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here row = row
+    // of x inside its 32-block, col = output column.  In round mb every wave parks its accumulator block; wave w then finishes registers
+    // 4w .. 4w+3 of the block for all lanes.
+    float bias = 0.0f;
+    const uint32_t ncol = n0 + (uint32_t)r;
+    if (bias_ != nullptr && ncol < n_rows) {
+        const uint16_t b = *reinterpret_cast<const uint16_t*>(bias_ + (size_t)ncol * 2);
+        if constexpr (OUT == OUT_F16) bias = (float)__builtin_bit_cast(_Float16, b);
+        else bias = bits_f32((uint32_t)b << 16);
+    }
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        __syncthreads();                                                           // main loop / previous round done with smem
+#pragma unroll
+        for (int i = 0; i < 16; i++) red[(wave * 16 + i) * 64 + lane] = acc[mb][i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = wave * 4 + k;
+            float v = red[(0 * 16 + i) * 64 + lane];
+            v += red[(1 * 16 + i) * 64 + lane];
+            v += red[(2 * 16 + i) * 64 + lane];
+            v += red[(3 * 16 + i) * 64 + lane];
+            v += bias;
+            const uint32_t mr = m0 + (uint32_t)(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+            if (mr < m && ncol < n_rows) {
+                uint16_t o;
+                if constexpr (OUT == OUT_F16) o = __builtin_bit_cast(uint16_t, (_Float16)v);
+                else o = (uint16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+                *reinterpret_cast<uint16_t*>(y_ + ((size_t)mr * n_rows + ncol) * 2) = o;
+            }
+        }
+    }
+}
+
+}  // namespace ggq

@@ -1,0 +1,93 @@
+"""Fused dequantize + GEMM on the matrix cores (include/ggq.h ggq_linear_mfma, opt-in) on an MI355X.
+
+A floating-point contraction: parity is a tolerance against an fp64 evaluation of the same op on the ORACLE's weights (the
+reference's values, cast to the activation dtype as dequantize_tensor does), with the worst-case fp32-accumulation bound of
+tests/test_gpu_linear.py -- plus cases where the fp32 sums are EXACT (integer-valued activations, power-of-two scales) and the
+result must therefore equal the correctly rounded fp64 value bit for bit: a dropped or duplicated chunk cannot hide in those.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_gpu_linear import _check, _dense_weight, DT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ALL = ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"]
+
+
+@pytest.mark.parametrize("name", ALL)
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_mfma_linear_against_fp64_reference(pkg, name, kind):
+    q = pkg.qtypes.Q[name]
+    dtype, eps = DT[kind]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(9)
+    # (rows, cols, m, bias, tile): ragged output columns (rows % 32), ragged rows of x (m % 32), one row, several tiles of x,
+    # 1 .. 12 spans of K (fewer spans than waves; not a multiple of the 4-way split)
+    for rows, cols, m, with_bias, tile in ((203, 3072, 1, True, 0), (17, 256, 40, False, 0), (64, 768, 33, True, 32), (96, 1024, 300, False, 64),
+                                           (333, 512, 129, True, 128), (40, 2304, 260, True, 256), (32, 1280, 96, False, 0)):
+        blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
+        bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if with_bias else None
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile)
+        assert y.shape == (m, rows) and y.dtype == dtype
+        _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
+        assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=tile))          # deterministic: fixed reduction order
+
+
+def _exact_blocks(pkg, q, rows, cols, seed):
+    """Packed blocks whose scale fields are powers of two: every weight, every product with a small integer and every partial
+    sum is exactly representable in fp32."""
+    blocks = pkg.synth.make_blocks(q, rows * cols // pkg.qtypes.block_geometry(q)[0], seed=seed, mode="raw")
+    for off in pkg.qtypes.SCALE_FIELDS[q]:
+        blocks[:, off], blocks[:, off + 1] = 0x00, 0x1C           # fp16 0x1C00 = 2^-8
+    return blocks.reshape(-1)
+
+
+@pytest.mark.parametrize("name", ["Q8_0", "Q4_0", "Q5_1", "Q4_K", "Q2_K", "Q6_K"])
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_exact_arithmetic_cases_are_bit_equal(pkg, name, kind):
+    """Integer-valued x in [-4, 4], scales 2^-8: all products and all fp32 partial sums are exact whatever their order, so BOTH
+    fused kernels must return the correctly rounded exact value -- bit for bit (Weak #3)."""
+    q = pkg.qtypes.Q[name]
+    dtype, _ = DT[kind]
+    rows, cols = 70, 1536
+    blocks = _exact_blocks(pkg, q, rows, cols, seed=77)
+    w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+    w64 = _dense_weight(q, blocks, kind, rows, cols)
+    assert np.all(w64 * 2.0 ** 8 == np.round(w64 * 2.0 ** 8)) and np.abs(w64).max() < 64       # every weight a multiple of 2^-8
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for m, fn in ((37, pkg.fused.linear_mfma), (3, pkg.fused.linear_small), (160, pkg.fused.linear_mfma)):
+        x = torch.randint(-4, 5, (m, cols), device=DEV, generator=g).to(dtype)
+        x64 = x.double().cpu().numpy()
+        assert (np.abs(x64) @ np.abs(w64).T).max() < 2.0 ** 16       # every partial sum, in ANY order, is a multiple of 2^-8 below 2^16: exact in fp32
+        exact = x64 @ w64.T
+        want = torch.from_numpy(exact).to(dtype)                                             # ONE rounding, as the kernel's store
+        got = fn(x, w)
+        assert torch.equal(got.cpu(), want), (name, kind, m)
+
+
+def test_mfma_linear_limits(pkg):
+    Q, ops, GGQUnsupported = pkg.qtypes.Q, pkg.ops, pkg.dequant.GGQUnsupported
+    mk = lambda q, shape, **kw: ops.GGMLTensor(torch.from_numpy(pkg.synth.make_tensor_bytes(q, shape, seed=1)).to(DEV), tensor_type=q, tensor_shape=shape, **kw)
+    x = torch.randn(8, 512, device=DEV, dtype=torch.bfloat16)
+    w = mk(Q.Q4_K, (64, 512))
+    y = pkg.fused.linear_mfma(x.reshape(2, 4, 512), w)
+    assert y.shape == (2, 4, 64)
+    assert torch.equal(pkg.fused.linear_mfma(x.t().contiguous().t(), w), y.reshape(8, 64))   # non-contiguous x: handled by a copy
+    for bad in (lambda: pkg.fused.linear_mfma(x.float(), w),                                  # fp32 activations
+                lambda: pkg.fused.linear_mfma(x, w, dequant_dtype=torch.float32),
+                lambda: pkg.fused.linear_mfma(x[:, :128], mk(Q.Q8_0, (64, 128))),             # cols % 256
+                lambda: pkg.fused.linear_mfma(x, mk(Q.Q4_K, (64, 512), patches=[("p", "k")])),
+                lambda: pkg.fused.linear_mfma(x.cpu(), w),
+                lambda: pkg.fused.linear_mfma(x, w, tile_rows=48)):
+        with pytest.raises(GGQUnsupported):
+            bad()
+    lib, nat = pkg._native.lib(), pkg._native
+    assert lib.ggq_linear_mfma(99, 16, 32, 256, 16, 1, None, 16, 1, 0, None) == nat.GGQ_ERR_QTYPE
+    assert lib.ggq_linear_mfma(12, 16, 32, 256, 16, 1, None, 16, 2, 0, None) == nat.GGQ_ERR_ARG      # fp32
+    assert lib.ggq_linear_mfma(12, 24, 32, 256, 16, 1, None, 16, 1, 0, None) == nat.GGQ_ERR_ALIGN
+    assert lib.ggq_linear_mfma(12, None, 0, 256, None, 1, None, None, 1, 0, None) == nat.GGQ_OK       # nothing to do
