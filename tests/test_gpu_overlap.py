@@ -136,9 +136,13 @@ def test_default_leaves_resident_weights_alone(pkg):
         res = _layers(pkg, SPECS[:3], "cuda:0", seed=5)
         low = _layers(pkg, SPECS[:3], "cpu", seed=5)
         xs = _inputs(res, 4, torch.bfloat16)
-        for _ in range(3):
-            for (a, _, _), (b, _, _), x in zip(res, low, xs):
-                assert torch.equal(a(x), b(x))
+        want = []
+        for _ in range(3):                                      # resident weights: the plain path, every call
+            want = [a(x) for (a, _, _), x in zip(res, xs)]
+        assert pf.stats()["bypassed"] == 9 and pf.stats()["hits"] == pf.stats()["misses"] == 0
+        for _ in range(3):                                      # the same layers with CPU-resident packed weights: prefetched
+            for (b, _, _), x, w in zip(low, xs, want):
+                assert torch.equal(b(x), w)
         st = pf.stats()
         assert st["bypassed"] == 9 and st["hits"] > 0 and st["pinned_host_bytes"] > 0
     finally:
