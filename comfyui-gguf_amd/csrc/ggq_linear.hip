@@ -101,9 +101,11 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     if (rows == 0 || m == 0) return GGQ_OK;
     if (!packed || !x || !y) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
-    // tile_rows: rows of x per workgroup tile (32, 64, 128, 256); 0 = pick from m (the smallest tile that covers m, at most 128)
+    // tile_rows: rows of x per workgroup tile (32, 64, 128, 256); 0 = pick from m.  Measured on FLUX / T5 layer shapes
+    // (profiles/r02_mfma_linear_tile_sweep.txt): one 32-row block up to m = 32; 64-row tiles from there to m ~ 384 (two blocks share
+    // every decoded weight, and twice as many workgroups as with 128-row tiles); 128-row tiles beyond.
     int shape;
-    if (tile_rows == 0) shape = m <= 32 ? 0 : (m <= 64 ? 1 : 2);
+    if (tile_rows == 0) shape = m <= 32 ? 0 : (m < 384 ? 1 : 2);
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
     const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));

@@ -19,7 +19,7 @@
 //     decoded ONCE per workgroup; at the end the four partial accumulators are summed through LDS in a fixed order (deterministic);
 //   * per span a wave copies the span's packed bytes of its 32 weight rows (32 x 144 B for Q4_K) into its private LDS slice with
 //     16 B/lane loads -- the next span's bytes are already in flight in registers -- then runs 16 k-steps: decode one chunk
-//     (~35-45 VALU lane-ops), MB MFMAs (32 cycles each) against MB A fragments loaded straight from global memory / L2;
+//     (~35-45 VALU lane-ops), MB MFMAs (32 cycles each) against MB A fragments (see linear_mfma below for how they are fetched);
 //   * no __syncthreads in the main loop (waves share nothing until the reduction).
 //
 // Numerics: the WEIGHTS are the reference's values bit for bit (same decode, same fp16 op sequence, then the `.to(dtype)` of
@@ -56,7 +56,16 @@ template <class F> struct MfmaGeom {
     static constexpr int SLICE = NUW * 64 * 16;                                    // LDS bytes per wave
 };
 
-// MB = 32-row blocks of x per workgroup tile (1, 2, 4, 8)
+// MB = 32-row blocks of x per workgroup tile (1, 2, 4, 8).
+// How a wave gets its A fragments (x): with ONE block of rows (MB = 1) straight from global memory -- lane (r, h) reads its 64
+// contiguous bytes of a 64-element span, the 2 KiB a wave touches per step stay in the vector L1.  With MB >= 2 that pattern
+// (32 B of each 128-B line per instruction) overflows the L1 -- 4 waves x MB x 4 KiB per step -- and every line is fetched from L2
+// several times (measured: a 128-row tile ran 2.5x SLOWER than four 32-row tiles).  So for MB >= 2 the wave first copies a
+// (MB*32 rows x 32 elements) piece of x into its own LDS slice with coalesced 16 B/lane loads (4 lanes per row: whole 64-B
+// sectors, each fetched once; the next piece is already in flight in registers) and reads the fragments back with ds_read_b128;
+// rows are 80 bytes apart in LDS, so the 16 lanes of a read phase hit 16 different 16-byte bank groups.
+constexpr int MF_XPITCH = 80;
+
 template <class F, int OUT, int MB>
 __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                              const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
@@ -66,7 +75,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
     constexpr int CPB = F::BS / 8;                                                 // chunks per block
     constexpr int RED = 16 * 64 * 4;                                               // one accumulator block of one wave, bytes
-    __shared__ __attribute__((aligned(16))) uint8_t smem[(MF_WAVES * G::SLICE > MF_WAVES * RED) ? MF_WAVES * G::SLICE : MF_WAVES * RED];
+    constexpr bool XLDS = MB >= 2;
+    constexpr int XS = XLDS ? MB * 32 * MF_XPITCH : 0;                             // LDS bytes per wave for its piece of x
+    constexpr int PER_WAVE = G::SLICE + XS;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[(MF_WAVES * PER_WAVE > MF_WAVES * RED) ? MF_WAVES * PER_WAVE : MF_WAVES * RED];
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -75,17 +87,12 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
     const gcptr packed = (gcptr)packed_;
     const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
     const uint32_t n_spans = cols / MF_SPAN;
-    uint8_t* slice = smem + wave * G::SLICE;
+    uint8_t* slice = smem + wave * PER_WAVE;
+    uint8_t* xs = slice + G::SLICE;
 
-    // the weight row this lane decodes, and the rows of x it feeds (clamped at the edges: the stores are masked instead)
+    // the weight row this lane decodes (clamped at the edge: the stores are masked instead)
     const uint32_t wrow = (n0 + (uint32_t)r < n_rows) ? n0 + (uint32_t)r : n_rows - 1;
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
-    GGQ_GLOBAL const uint8_t* xrow[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++) {
-        const uint32_t mr = m0 + (uint32_t)(mb * 32 + r);
-        xrow[mb] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
-    }
 
     // copy of one span's packed bytes for the 32 rows: unit = (row, 16-byte piece); lane takes units lane, lane + 64, ...
     auto fetch = [&](uint32_t span, u32x4 (&pf)[G::NUW]) {
@@ -106,35 +113,84 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[mb][i] = 0.0f;
 
+    // one k-step: decode chunk j of the span (8 weights of row r) and run it against the MB fragments of x
+    auto step = [&](const uint8_t* wspan, int j, const u32x4 (&xa)[MB]) {
+        const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, j % CPB);
+        uint32_t w[4];
+        weights8<F, OUT>(f, w);
+        const u32x4 wb{w[0], w[1], w[2], w[3]};
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) acc[mb] = mfma32<OUT>(xa[mb], wb, acc[mb]);
+    };
+
     u32x4 pf[G::NUW];
     if ((uint32_t)wave < n_spans) fetch((uint32_t)wave, pf);
-    for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
+
+    if constexpr (!XLDS) {
+        const uint32_t mr = m0 + (uint32_t)r;
+        const GGQ_GLOBAL uint8_t* xrow = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
+        for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
 #pragma unroll
-        for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
-        wave_sync();
-        if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);                 // the next span's bytes fly while this one is decoded
-        const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
-        const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
-        const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
+            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+            wave_sync();
+            if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);             // the next span's bytes fly while this one is decoded
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
+            const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
+            const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {                                              // 64 contraction elements per q
-            u32x4 xa[MB][4];
+            for (int q = 0; q < 4; q++) {                                          // 64 contraction elements per q: k = 64 q + 32 h + 8 s .. + 7
+                u32x4 xq[4];
 #pragma unroll
-            for (int mb = 0; mb < MB; mb++)
+                for (int s4 = 0; s4 < 4; s4++) xq[s4] = *(GGQ_GLOBAL const u32x4*)(xrow + kbyte + (uint32_t)(q * 128 + s4 * 16));
 #pragma unroll
-                for (int s = 0; s < 4; s++) xa[mb][s] = *(GGQ_GLOBAL const u32x4*)(xrow[mb] + kbyte + (uint32_t)(q * 128 + s * 16));
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const u32x4 xa[MB] = {xq[s4]};
+                    step(wspan, 8 * q + 4 * h + s4, xa);
+                }
+            }
+            wave_sync();                                                           // the slice is rewritten at the top of the loop
+        }
+    } else {
+        // pieces of x: (MB*32 rows) x (32 elements = 64 bytes); lane -> (row lane/4 + 16 i, 16-byte piece lane%4), MB*2 loads per piece
+        constexpr int NX = MB * 2;
+        const int lrow = lane >> 2, lpc = lane & 3;
+        const GGQ_GLOBAL uint8_t* xsrc[NX];
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int j = 8 * q + 4 * h + s;                                   // chunk of the span: k = 64 q + 32 h + 8 s .. + 7
-                const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, j % CPB);
-                uint32_t w[4];
-                weights8<F, OUT>(f, w);
-                const u32x4 wb{w[0], w[1], w[2], w[3]};
+        for (int i = 0; i < NX; i++) {
+            const uint32_t mr = m0 + (uint32_t)(lrow + 16 * i);
+            xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(lpc * 16);
+        }
+        u32x4 xr[NX];
+        auto xfetch = [&](uint32_t kb) {
 #pragma unroll
-                for (int mb = 0; mb < MB; mb++) acc[mb] = mfma32<OUT>(xa[mb][s], wb, acc[mb]);
+            for (int i = 0; i < NX; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
+        };
+        if ((uint32_t)wave < n_spans) xfetch((uint32_t)wave * (uint32_t)(MF_SPAN * 2));
+        for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
+#pragma unroll
+            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+            wave_sync();
+            if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
+            const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
+            const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {                                          // 32 contraction elements per t: k = 32 t + 16 h + 8 s .. + 7
+#pragma unroll
+                for (int i = 0; i < NX; i++) *reinterpret_cast<u32x4*>(xs + (lrow + 16 * i) * MF_XPITCH + lpc * 16) = xr[i];
+                wave_sync();
+                if (t < 7) xfetch(kbyte + (uint32_t)((t + 1) * 64));
+                else if (span + MF_WAVES < n_spans) xfetch((span + MF_WAVES) * (uint32_t)(MF_SPAN * 2));
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    u32x4 xa[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) xa[mb] = *reinterpret_cast<const u32x4*>(xs + (mb * 32 + r) * MF_XPITCH + h * 32 + s2 * 16);
+                    step(wspan, 4 * t + 2 * h + s2, xa);
+                }
+                wave_sync();                                                       // xs is rewritten at the top of the t loop
             }
         }
-        wave_sync();                                                               // the slice is rewritten at the top of the loop
     }
 
     // ---- sum the four K-partials through LDS, fixed order (wave 0 + 1 + 2 + 3), then bias, cast, store.

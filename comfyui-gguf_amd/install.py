@@ -19,6 +19,11 @@ in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM 
 linear kernel (fused.py) when weight and input qualify, everything else -- LoRA-patched weights included -- through the
 reference's method.  Opt-in because the result matches F.linear up to fp32 summation order, not bit for bit.
 
+``fused_mfma`` (or ``GGQ_FUSED_MFMA=1``; needs ``ref_ops``) wraps the same method for inputs of up to ``fused_mfma_max_m`` rows
+(default 256, ``GGQ_FUSED_MFMA_MAX_M``): fused dequantize + GEMM on the matrix cores (fused.linear_mfma), 1.2-3x faster than
+dequantize + hipBLASLt in that range on FLUX / T5 layer shapes; above it hipBLASLt on the dense weight wins and keeps the job.
+Same opt-in reasoning: fp32 summation order.
+
 ``gather_embedding`` (or ``GGQ_GATHER_EMBEDDING=1``; needs ``ref_ops``) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights``
 (reference ops.py:251-260): instead of dequantizing the whole table and then gathering, only the rows the token ids name are
 unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense table (a 152 k x 3584 vocabulary is 1.1 GB).
@@ -40,7 +45,8 @@ from . import dequant as _hip
 _installed = {}
 
 
-def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None):
+def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
+            fused_mfma=None, fused_mfma_max_m=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -85,10 +91,14 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
             patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
     if fused_small_m is None:
         fused_small_m = os.environ.get("GGQ_FUSED_SMALL_M", "0") not in ("", "0")
-    if fused_small_m:
+    if fused_mfma is None:
+        fused_mfma = os.environ.get("GGQ_FUSED_MFMA", "0") not in ("", "0")
+    if fused_mfma_max_m is None:
+        fused_mfma_max_m = int(os.environ.get("GGQ_FUSED_MFMA_MAX_M", "256"))
+    if fused_small_m or fused_mfma:
         if ref_ops is None:
-            raise ValueError("fused_small_m patches GGMLOps.Linear: pass ref_ops")
-        patched.append(_fuse_small_m(ref_ops.GGMLOps.Linear, unsupported))
+            raise ValueError("fused_small_m / fused_mfma patch GGMLOps.Linear: pass ref_ops")
+        patched.append(_fuse_linear(ref_ops.GGMLOps.Linear, unsupported, bool(fused_small_m), fused_mfma_max_m if fused_mfma else 0))
     if gather_embedding is None:
         gather_embedding = os.environ.get("GGQ_GATHER_EMBEDDING", "0") not in ("", "0")
     if gather_embedding:
@@ -131,16 +141,23 @@ def _gather_embedding(embedding_cls, unsupported):
     return (embedding_cls, "forward_ggml_cast_weights", reference_forward)
 
 
-def _fuse_small_m(linear_cls, unsupported):
-    """Wrap ``linear_cls.forward_ggml_cast_weights``; returns the (owner, name, original) record uninstall() restores."""
-    from .fused import MAX_ROWS, linear_small
+def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
+    """Wrap ``linear_cls.forward_ggml_cast_weights``: inputs of 1..4 rows -> fused.linear_small (when ``small_m``), inputs of up
+    to ``mfma_max_m`` rows -> fused.linear_mfma; everything else, and everything either kernel declines, -> the reference's method.
+    Returns the (owner, name, original) record uninstall() restores."""
+    from .fused import MAX_ROWS, linear_mfma, linear_small
     reference_forward = linear_cls.forward_ggml_cast_weights
 
     def forward_ggml_cast_weights(self, input):
         weight = self.weight
-        if input.numel() <= MAX_ROWS * input.shape[-1] and weight is not None and input.is_cuda:
+        if weight is not None and input.is_cuda:
+            cols = input.shape[-1]
+            m = input.numel() // cols if cols else 0
             try:
-                return linear_small(input, weight.to(input.device), self.bias, self.dequant_dtype)
+                if small_m and m <= MAX_ROWS:
+                    return linear_small(input, weight.to(input.device), self.bias, self.dequant_dtype)
+                if m <= mfma_max_m:
+                    return linear_mfma(input, weight.to(input.device), self.bias, self.dequant_dtype)
             except unsupported:
                 pass
         return reference_forward(self, input)

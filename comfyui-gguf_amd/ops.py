@@ -98,10 +98,11 @@ class GGMLLayer(torch.nn.Module):
 
 
 class GGMLLinear(GGMLLayer):
-    """``GGMLOps.Linear`` (ops.py:227-244).  ``fuse_small_m`` (opt-in, fused.py): inputs of at most four rows go through the
-    fused dequantize + linear kernel instead of dequantize-then-F.linear."""
+    """``GGMLOps.Linear`` (ops.py:227-244).  ``fuse_small_m`` / ``fuse_mfma_max_m`` (opt-in, fused.py): inputs of at most four rows /
+    of at most that many rows go through a fused dequantize + linear kernel instead of dequantize-then-F.linear."""
 
     fuse_small_m = False
+    fuse_mfma_max_m = 0                            # opt-in: inputs of up to this many rows go through fused.linear_mfma
 
     def forward(self, input):
         if self.fuse_small_m and is_quantized(self.weight) and input.numel() <= 4 * input.shape[-1]:
@@ -109,6 +110,13 @@ class GGMLLinear(GGMLLayer):
             from .dequant import GGQUnsupported
             try:
                 return linear_small(input, self.weight.to(input.device), self.bias, self.dequant_dtype)
+            except GGQUnsupported:
+                pass
+        if self.fuse_mfma_max_m and is_quantized(self.weight) and input.numel() <= self.fuse_mfma_max_m * input.shape[-1]:
+            from .fused import linear_mfma
+            from .dequant import GGQUnsupported
+            try:
+                return linear_mfma(input, self.weight.to(input.device), self.bias, self.dequant_dtype)
             except GGQUnsupported:
                 pass
         if not self.is_ggml_quantized():

@@ -112,7 +112,7 @@ def test_install_fused_small_m_wraps_the_linear_forward(pkg):
     lin = Linear(w)
     x = torch.randn(1, 1024, device=DEV, dtype=torch.float16)
     ref = lin(x)
-    record = pkg.install._fuse_small_m(Linear, pkg.dequant.GGQUnsupported)
+    record = pkg.install._fuse_linear(Linear, pkg.dequant.GGQUnsupported, True, 0)
     try:
         before = Linear.calls
         y = lin(x)

@@ -202,6 +202,31 @@ def test_reference_linear_fused_small_m(mods, pkg, dev, monkeypatch):
         assert counter.n == n + 6
 
 
+def test_reference_linear_fused_mfma(mods, pkg, dev, monkeypatch):
+    """install(fused_mfma=True): up to fused_mfma_max_m rows go through the MFMA kernel (tolerance vs fp64 on the oracle's weights);
+    more rows, fp32 inputs and LoRA-patched layers keep the reference's method bit for bit."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, packed = H.make_linear(ro, pkg, Q.Q5_K, 80, 1024, dev, seed=4)
+    lora, _ = H.make_linear(ro, pkg, Q.Q5_K, 80, 1024, dev, seed=4, patches=H.lora_patch((80, 1024), seed=6))
+    xs = {m: torch.randn(m, 1024, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(m)) for m in (3, 48, 200, 300)}
+    want = {m: lin(x) for m, x in xs.items()}
+    want_lora = {m: lora(x) for m, x in xs.items()}
+    want32 = lin(xs[48].float())
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    with H.Installed(pkg, mods, fused_mfma=True, fused_mfma_max_m=256):
+        assert torch.equal(lin(xs[300]), want[300]) and counter.n == 1            # above the threshold: dequantize + F.linear
+        assert torch.equal(lin(xs[48].float()), want32) and counter.n == 2        # fp32 activations: not the kernel's business
+        w64 = H.oracle_tensor(Q.Q5_K, packed, torch.bfloat16, None, (80, 1024)).double()
+        for m in (3, 48, 200):
+            got = lin(xs[m])
+            assert counter.n == 2 and got.dtype == torch.bfloat16 and got.shape == (m, 80)
+            ref = xs[m].cpu().double() @ w64.T + torch.Tensor(lin.bias).cpu().double()
+            tol = 1024 * 2.0 ** -24 * (xs[m].cpu().double().abs() @ w64.abs().T) + 2.0 ** -8 * ref.abs() + 1e-30
+            assert bool(((got.cpu().double() - ref).abs() <= tol).all())
+            assert torch.equal(lora(xs[m]), want_lora[m])                           # patched: the reference's method
+        assert counter.n == 2 + 3
+
+
 @pytest.mark.parametrize("qname", ["Q4_0", "Q8_0", "Q4_K", "Q6_K", "IQ4_XS"])
 @pytest.mark.parametrize("gather", [False, True], ids=["two-step", "gather_embedding"])
 def test_reference_embedding_forward(mods, pkg, dev, monkeypatch, qname, gather):
