@@ -134,6 +134,7 @@ def check_no_fma(asm_text):
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 into comfyui-gguf_amd/_lib/ (cross-compiles without a GPU)."""
     global _lib
+    build_fast(force)
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -156,6 +157,46 @@ def build(force=False, verbose=False):
         os.replace(LIB_PATH + ".tmp", LIB_PATH)
     _lib = None
     return LIB_PATH
+
+
+FAST_SRC = os.path.join(CSRC, "ggq_pyfast.c")
+
+
+def fast_path():
+    import sysconfig
+    return os.path.join(LIB_DIR, "_ggq_fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_fast(force=False):
+    """gcc the optional CPython binding of ggq_dequant (csrc/ggq_pyfast.c).  Returns its path, or None when Python.h / gcc are
+    not there -- dequant.py then keeps calling through ctypes."""
+    import sysconfig
+    out = fast_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(FAST_SRC):
+        return out
+    inc = sysconfig.get_paths().get("include")
+    gcc = shutil.which("gcc")
+    if not gcc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    os.makedirs(LIB_DIR, exist_ok=True)
+    proc = subprocess.run([gcc, "-O2", "-shared", "-fPIC", "-I" + inc, FAST_SRC, "-o", out + ".tmp"], capture_output=True, text=True)
+    if proc.returncode:
+        raise GGQNativeError(f"gcc failed on ggq_pyfast.c:\n{proc.stderr[-2000:]}")
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def fast():
+    """The _ggq_fast module bound to the loaded library's ggq_dequant, or None if it has not been built."""
+    path = fast_path()
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ggq_fast", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.bind(ctypes.cast(lib().ggq_dequant, ctypes.c_void_p).value)
+    return mod
 
 
 def lib():

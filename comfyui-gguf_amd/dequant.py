@@ -85,7 +85,16 @@ except AttributeError:                                     # torch built without
         return torch.cuda.current_device()
 
 _NoTorchFunction = torch._C.DisableTorchFunctionSubclass
-_ggq_dequant = None
+_ggq_dequant = None     # ggq_dequant(qtype, packed, n_blocks, out, compute, out_dtype, stream) -> status: _ggq_fast.dequant (CPython
+                        # binding, csrc/ggq_pyfast.c) when it has been built, else the ctypes function -- the same C entry point
+_fast = None
+
+
+def _bind():
+    global _ggq_dequant, _fast
+    _fast = _native.fast()
+    _ggq_dequant = _fast.dequant if _fast is not None else _native.lib().ggq_dequant
+    return _ggq_dequant
 
 # libggq_hip.so holds gfx950 code objects only.  A GPU of any other architecture (another AMD part, or an NVIDIA device in a
 # CUDA build of torch) is "not served here", exactly like a CPU tensor: GGQUnsupported, so that under install() the reference's
@@ -107,9 +116,8 @@ def _device_served(index):
 
 def _launch(qtype, data, n_blocks, out, compute_code, out_code):
     """Enqueue on torch's CURRENT stream of data's device: orders after the H2D copy, before F.linear."""
-    global _ggq_dequant
     if _ggq_dequant is None:
-        _ggq_dequant = _native.lib().ggq_dequant
+        _bind()
     index = data.device.index
     if not (_DEVICE_OK.get(index) or _device_served(index)):
         raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
@@ -220,7 +228,52 @@ def dequantize(data, qtype, oshape, dtype=None):
 def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
     """dequant.py:15-28, same argument meaning and result."""
     qtype = getattr(tensor, "tensor_type", None)
-    oshape = getattr(tensor, "tensor_shape", tensor.shape)
+    try:
+        ent = _HIP_TABLE.get(qtype)
+    except TypeError:                                   # an unhashable "qtype": the general path names it in its error
+        ent = None
+    if ent is not None and dtype in _OUT_CODE and not _is_compiling():
+        # ---- the per-layer hot loop (ops.py:177): a quantized GGMLTensor on the GPU, a result dtype the kernels emit.  Everything
+        # the general path below does, flattened into one frame: each avoided call / lookup is ~0.1 us of a ~7 us call.
+        cd = dtype if dequant_dtype == "target" else dequant_dtype
+        try:
+            compute_code = _COMPUTE_CODE[cd]
+        except (KeyError, TypeError):
+            raise GGQUnsupported(f"dequant_dtype={cd}: the HIP kernels compute in float16, bfloat16 or float32") from None
+        oshape = getattr(tensor, "tensor_shape", None)
+        if oshape is not None and isinstance(tensor, torch.Tensor):
+            qid, block_size, type_size = ent
+            with _NoTorchFunction():
+                data = tensor
+                if not data.is_cuda:
+                    raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
+                if data.dtype is not torch.uint8 or not data.is_contiguous() or data.data_ptr() & 15:
+                    data = _as_bytes(data)                      # views, other storage dtypes, misaligned starts
+                n_blocks = data.numel() // type_size            # dequant.py:41
+                device = data.device
+                out = torch.empty(oshape, dtype=dtype, device=device)
+                if out.numel() != n_blocks * block_size:
+                    raise RuntimeError(f"shape '{list(oshape)}' is invalid for input of size {n_blocks * block_size}")   # what .reshape(oshape) raises
+                if n_blocks:
+                    index = device.index
+                    if not (_DEVICE_OK.get(index) or _device_served(index)):
+                        raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
+                    if _cur_device() != index:
+                        _launch(qid, data, n_blocks, out, compute_code, _OUT_CODE[dtype])
+                    else:
+                        rc = (_ggq_dequant or _bind())(qid, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, _OUT_CODE[dtype], _raw_stream(index))
+                        if rc:
+                            _native.check(rc, f"ggq_dequant({Q(qid).name})")
+            return out
+    return _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype)
+
+
+def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype):
+    """dequant.py:15-28 for everything the hot path above does not take: passthrough types, plain-int qtypes, result dtypes the
+    kernels do not emit, carriers that are not tensors, BF16, tracing under torch.compile, unknown qtypes."""
+    oshape = getattr(tensor, "tensor_shape", None)
+    if oshape is None:
+        oshape = tensor.shape
 
     if qtype in TORCH_COMPATIBLE_QTYPES:
         return tensor.to(dtype)

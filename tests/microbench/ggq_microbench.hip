@@ -364,12 +364,13 @@ static uint64_t pool_align()
     return a ? a : 256;
 }
 
-static Pool make_pool(const QT& q, int pairs)
+static Pool make_pool(const QT& q, int pairs, uint64_t only_elements = 0)
 {
     const uint64_t A = pool_align();
     Pool P; P.bs = ggq_oracle_block_size(q.id); P.ts = ggq_oracle_type_size(q.id);
     const uint64_t shapes[2] = {3072ull * 3072, 3072ull * 12288};
-    for (int i = 0; i < pairs; i++) for (uint64_t el : shapes) { P.nblk.push_back(el / P.bs); P.elements += el; }
+    if (only_elements) { for (int i = 0; i < pairs; i++) { P.nblk.push_back(only_elements / P.bs); P.elements += only_elements; } }
+    else for (int i = 0; i < pairs; i++) for (uint64_t el : shapes) { P.nblk.push_back(el / P.bs); P.elements += el; }
     for (uint64_t nb : P.nblk) { P.packed_bytes += (nb * P.ts + A - 1) / A * A; }
     P.out_bytes = P.elements * 2;
     HIP_CHECK(hipMalloc(&P.packed, P.packed_bytes)); HIP_CHECK(hipMalloc(&P.out, P.out_bytes));
@@ -622,6 +623,45 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
     if (dyn_lds > 0) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384));
     ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ggq::AR_F16, COOP>), dim3(blocks), dim3(WAVES * 64), dyn_lds, nullptr, dt, n, groups, xrun, nullptr, 0u); },
                              (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, XCD, DIRECT, THR, R, COOP>()});
+}
+
+// Round 2: LAYER-SIZED launches -- one dequant_one per tensor, tensor after tensor, as ComfyUI issues them (ops.py:177) -- where a launch
+// is 1-5 dispatch rounds of workgroups and ramp / tail / drain are a third of the time.  One "launch" of the AB = one pass over the pool.
+template <class F, int G, int WAVES, bool COOP, bool NTL = true>
+static void ab_add_layer(AB& ab, const char* name, Pool& P, uint32_t xrun, int dyn_lds = 0)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s layer %s G=%d waves=%d ntl=%d xrun=%u dynlds=%dK", name, COOP ? "coop" : "solo", G, WAVES, (int)NTL, xrun, dyn_lds / 1024);
+    ab.v.push_back(ABVariant{buf, [=] {
+                                 for (const ggq::Desc& t : d) {
+                                     const uint64_t groups = (t.n_blocks + G - 1) / G;
+                                     hipLaunchKernelGGL((ggq::lab::dequant_one<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP>),
+                                                        dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), dyn_lds, nullptr, t, groups, xrun);
+                                 }
+                             },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, true, WAVES, 0, false, -1, 1, COOP>()});
+}
+
+template <class F, int GB /* blocks per 2048 elements */>
+static void ab_layer(const char* name, int qi, std::initializer_list<uint64_t> sizes)
+{
+    for (uint64_t el : sizes) {
+        const int n_t = (int)std::max<uint64_t>(6, std::min<uint64_t>(48, (600ull << 20) / (el * 2)));   // dense bytes of the pool > 2x the Infinity Cache
+        Pool Q = make_pool(QTS[qi], n_t, el);
+        printf("LAYER %s: %d tensors of %llu elements (%.1f M), one launch each\n", name, n_t, (unsigned long long)el, el / 1e6);
+        AB ab;
+        ab_add_layer<F, 2 * GB, 4, true>(ab, name, Q, 0);          // shipped: 4 waves own 4096 elements (2 store rows per wave)
+        ab_add_layer<F, 2 * GB, 4, true>(ab, name, Q, 5);
+        ab_add_layer<F, 2 * GB, 2, true>(ab, name, Q, 0);          // 2 waves own 4096: 4 rows per wave, half as many waves
+        ab_add_layer<F, 2 * GB, 2, true>(ab, name, Q, 5);
+        ab_add_layer<F, 4 * GB, 4, true>(ab, name, Q, 0);          // 4 waves own 8192: 4 rows per wave
+        ab_add_layer<F, 4 * GB, 2, true>(ab, name, Q, 0);          // 2 waves own 8192: 8 rows per wave
+        ab_add_layer<F, GB, 4, false>(ab, name, Q, 0);             // one-wave teams x 2048, 4 per workgroup
+        ab_add_layer<F, GB, 1, false>(ab, name, Q, 0);             // one-wave teams x 2048
+        ab.run(12, 4);
+        free_pool(Q);
+    }
 }
 
 template <class F, int G>
@@ -1125,6 +1165,12 @@ int main(int argc, char** argv)
     if (what == "skel") skeletons();
     if (what == "pmc2") pmc2_sequence();
     if (what == "pmc3") pmc3_sequence();
+    if (what == "ablayer") {
+        // FLUX 3072x3072 / 9216x3072 / 12288x3072 / 21504x3072, T5 4096x4096, SD3.5 2432x2432 (as 23 x 256 x 1024) and 7296x2432, a small one
+        ab_layer<ggq::FmtQ4_K, 8>("Q4_K", 7, {1ull << 21, 23ull * 256 * 1024, 3072ull * 3072, 4096ull * 4096, 9216ull * 3072, 12288ull * 3072, 21504ull * 3072});
+        ab_layer<ggq::FmtQ5_0, 64>("Q5_0", 2, {2432ull * 2432, 7296ull * 2432, 3072ull * 3072});
+        ab_layer<ggq::FmtQ8_0, 64>("Q8_0", 4, {3072ull * 3072, 4096ull * 4096, 12288ull * 3072});
+    }
     if (what == "ab") ab_all();
     if (what == "abxcd") ab_xcd_all();
     if (what == "ceilx") ceilings_x();

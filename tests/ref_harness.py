@@ -112,15 +112,16 @@ class Installed:
 
 
 class LaunchCounter:
-    """Counts launches of the HIP dequant kernels made through the host mirror (dequant._launch): a GPU test that compares
-    "installed" with "reference" must also prove the installed side really ran the HIP path."""
+    """Counts calls of the C entry point ggq_dequant made by the host mirror (dequant._ggq_dequant: the one binding every
+    dequantize_tensor / dequantize / block-function call goes through): a GPU test that compares "installed" with "reference" must
+    also prove the installed side really ran the HIP path."""
 
     def __init__(self, pkg, monkeypatch):
         self.n = 0
-        real = pkg.dequant._launch
+        real = pkg.dequant._ggq_dequant or pkg.dequant._bind()
 
-        def counted(*a, **k):
+        def counted(*a):
             self.n += 1
-            return real(*a, **k)
+            return real(*a)
 
-        monkeypatch.setattr(pkg.dequant, "_launch", counted)
+        monkeypatch.setattr(pkg.dequant, "_ggq_dequant", counted)
