@@ -57,6 +57,22 @@ template <class F> struct TuneCoop {             // teams of 4 waves x 4096 elem
     static constexpr int WAVES = 4;
     static constexpr uint32_t XRUN_LOG2 = 5;
 };
+// Single tensors between one and four dispatch rounds of the shipped shapes (8.4 M ... 33.5 M elements: FLUX 3072x3072 and
+// 9216x3072, T5 4096x4096, SD3.5 7296x2432): teams of 4 waves x 8192 elements -- 4 store rows per wave, HALF as many waves, so a
+// 3072x3072 tensor is ONE round of resident workgroups instead of 1.125 (the 0.125 is a whole second latency chain on an almost
+// idle chip).  tests/microbench `ablayer`, one launch per tensor over pools > 2x the Infinity Cache
+// (profiles/r02_microbench_layer_sized_launch_shapes.txt): Q4_K 9.4 M elements 4323 -> 5110 GB/s, 16.8 M 4954 -> 5934, 28.3 M 5273 -> 5968;
+// Q5_0 17.7 M 4747 -> 5311; Q8_0 9.4 M 4717 -> 5267; level from 37.7 M up, and 3-4 % SLOWER below 8 M (one round either way).
+template <class F> struct TuneMid {
+    static constexpr int G = (F::BS == 256) ? 32 : 256;
+    static constexpr bool COOP = true, NTL = !PlainLoads<F>::V, NTS = true;
+    static constexpr int WAVES = 4;
+    static constexpr uint32_t XRUN_LOG2 = 0;
+};
+constexpr uint64_t MID_MIN_ELEMENTS = 1ull << 23, MID_MAX_ELEMENTS = 1ull << 25;
+template <class F> struct MidShape { static constexpr bool V = true; };
+template <> struct MidShape<FmtQ3_K> { static constexpr bool V = false; };      // not measured at layer size: keeps its shape
+
 // Tune<F> = the shape for the stock fp16 arithmetic and fp16 output; TuneFor<F, ARITH, OUT> below picks per mode.
 #ifdef GGQ_SOLO_ONLY      /* A/B builds only: one-wave teams for every format */
 template <class F> struct Tune : TuneSolo<F> {};
@@ -183,7 +199,11 @@ hipError_t run_one(const Desc& d, hipStream_t s)
 {
     using Big = TuneFor<F, ARITH, OUT>;                              // the shape of whole-model launches
     using Fp16Out = TuneFor<F, ARITH, OUT_F16>;
-    const bool layer_sized = d.n_blocks * (uint64_t)F::BS < XRUN_MIN_ELEMENTS;
+    const uint64_t elements = d.n_blocks * (uint64_t)F::BS;
+    if constexpr (MidShape<F>::V && OUT != OUT_F32) {                // (fp32 output already stores twice the rows per wave)
+        if (elements > MID_MIN_ELEMENTS && elements < MID_MAX_ELEMENTS) return launch_one<TuneMid<F>, F, ARITH, OUT>(d, s);
+    }
+    const bool layer_sized = elements < XRUN_MIN_ELEMENTS;
     if constexpr (SoloWhenSmall<F>::V && Big::COOP) {
         if (layer_sized) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
     }

@@ -156,6 +156,30 @@ def test_dequant_dtype_modes_full_size(pkg, name, compute):
     assert np.array_equal(_raw(got).view(u), want.view(u))                   # signed nominal scales: no NaN, raw bits
 
 
+@pytest.mark.parametrize("name", ALL)
+def test_layer_sized_tensors_all_modes_vs_oracle(pkg, name):
+    """Single tensors of 8.4 M ... 33.5 M elements take their own launch shape (teams of 4 waves x 8192 elements, ggq_capi.hip
+    TuneMid): one tensor of that size class per format -- not a whole number of groups -- in every (arithmetic -> output) mode the
+    shape serves, against the oracle; and the neighbouring size classes (just below / above) stay exact too."""
+    q = pkg.qtypes.Q[name]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    n = 9_437_184 // bs + 3                                       # 3072x3072 plus three blocks: a ragged last group
+    blocks = pkg.synth.make_blocks(q, n, seed=77, mode="signed")
+    t = _carrier(pkg, blocks, q)
+    for compute in ("f16", "bf16", "f32"):
+        for out in ("f16", "bf16", "f32"):
+            if compute != "f16" and out not in (compute, "bf16"):
+                continue                                           # the full 3 x 3 table runs at small sizes above
+            want = oracle.dequant_tensor(q, blocks, compute, out)
+            got = pkg.dequant.dequantize_tensor(t, _TORCH[out], dequant_dtype=None if compute == "f16" else _TORCH[compute])
+            u = np.uint32 if out == "f32" else np.uint16
+            assert np.array_equal(_raw(got).view(u), want.view(u)), (name, compute, out)
+    for n_el in ((1 << 23), (1 << 23) + 256 * 8, (1 << 25) - 256 * 8, (1 << 25)):                   # the class boundaries
+        blocks = pkg.synth.make_blocks(q, n_el // bs, seed=78, mode="signed")
+        got = pkg.dequant.dequantize_tensor(_carrier(pkg, blocks, q), torch.bfloat16)
+        assert np.array_equal(_raw(got).view(np.uint16), oracle.dequant_tensor(q, blocks, "f16", "bf16").view(np.uint16)), (name, n_el)
+
+
 def test_randomized_sweep(pkg):
     """500 seeded random (format, block count, scale mode, dequant_dtype, dtype) cases against the oracle -- block counts
     drawn around the group boundaries of both team shapes and at random up to 20000."""

