@@ -294,6 +294,32 @@ def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype):
                          "(the reference falls back to gguf's numpy dequantize here, dequant.py:24-28)")
 
 
+def dequantize_tensor_via_gpu(tensor, dtype=None, dequant_dtype=None, device=None):
+    """``dequantize_tensor`` for a CPU-RESIDENT quantized tensor, computed on the GPU: upload the packed bytes, unpack there,
+    copy the dense result back -- the result lives on the CPU, as the reference's does, and holds the same bits.  For the
+    load-time callers that dequantize big CPU tensors (token_embd / mmproj, reference loader.py:253-254,270,386,397): a T5-xxl
+    embedding table is 131 M elements, ~0.3-0.6 s of torch-CPU ops against tens of milliseconds of PCIe traffic.
+    Raises GGQUnsupported for anything that is not a CPU tensor of a type with a kernel (the caller keeps the reference's path)."""
+    qtype = getattr(tensor, "tensor_type", None)
+    key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
+    if key not in _HIP_TABLE or not isinstance(tensor, torch.Tensor):
+        raise GGQUnsupported("GPU route: a quantized tensor of a type with a HIP unpacker")
+    if dtype not in _OUT_CODE and dtype is not None:
+        raise GGQUnsupported("GPU route: fp16 / bf16 / fp32 results")
+    oshape = getattr(tensor, "tensor_shape", None)
+    with _NoTorchFunction():
+        if tensor.device.type != "cpu":
+            raise GGQUnsupported("GPU route is for CPU-resident tensors")
+        if device is None:
+            if not torch.cuda.is_available():
+                raise GGQUnsupported("no GPU to route through")
+            device = torch.device("cuda", torch.cuda.current_device())
+        data = _as_bytes(tensor, align=False).to(device, non_blocking=False)
+    from .ops import GGMLTensor
+    carrier = GGMLTensor(data, tensor_type=key, tensor_shape=oshape if oshape is not None else tensor.shape)
+    return dequantize_tensor(carrier, dtype, dequant_dtype).cpu()
+
+
 def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
     """``F.embedding(indices, dequantize_tensor(tensor, dtype, dequant_dtype))`` without unpacking the whole table: only the
     rows ``indices`` names are dequantized (include/ggq.h ``ggq_dequant_rows``), bit-identical values.  What

@@ -30,6 +30,11 @@ unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense t
 Tables the kernel does not take (CPU, F16 / F32 storage, ``max_norm`` set, LoRA patches) keep the
 reference's method.
 
+``cpu_route_mb`` (or ``GGQ_CPU_ROUTE_MB=N``): CPU-resident quantized tensors of at least N MB of packed bytes -- the load-time
+callers, token_embd / mmproj tables (reference loader.py:253-254,270,386,397) -- are uploaded, unpacked on the GPU and copied back
+(dequant.dequantize_tensor_via_gpu) instead of running the reference's torch-CPU ops: same bits, CPU result.  Off by default (it
+touches the GPU at load time, before ComfyUI's model management has placed anything).
+
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
 overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
 and unpacked on a side stream while the current layer's GEMM runs (``overlap="all"``: also for weights already in HBM, where it
@@ -46,7 +51,7 @@ _installed = {}
 
 
 def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
-            fused_mfma=None, fused_mfma_max_m=None):
+            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -74,10 +79,20 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         except unsupported:
             return orig_dequantize(data, qtype, oshape, dtype=dtype)
 
+    if cpu_route_mb is None and os.environ.get("GGQ_CPU_ROUTE_MB"):
+        cpu_route_mb = float(os.environ["GGQ_CPU_ROUTE_MB"])
+    route_bytes = int(cpu_route_mb * 1e6) if cpu_route_mb else 0
+    via_gpu = _hip.dequantize_tensor_via_gpu
+
     def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
         try:
             return hip_dequantize_tensor(tensor, dtype, dequant_dtype)
         except unsupported:
+            if route_bytes and isinstance(tensor, torch.Tensor) and tensor.device.type == "cpu" and tensor.numel() * tensor.element_size() >= route_bytes:
+                try:
+                    return via_gpu(tensor, dtype, dequant_dtype)
+                except unsupported:
+                    pass
             return orig_dequantize_tensor(tensor, dtype, dequant_dtype)
 
     dequantize.__wrapped__ = orig["dequantize"]

@@ -1,0 +1,102 @@
+"""The N > 1 path with REAL processes on the one GPU the test box has: `bench.py --gpus 2` launched the
+way the driver launches it (python -m torch.distributed.run, one process per rank), the ranks sharing device 0 and fencing
+through gloo (GGQ_BENCH_BACKEND=gloo -- RCCL needs one device per rank); and the sharded file -> HBM upload from two processes.
+What it proves: the launch contract, the sharding, the fences and the MAX-over-ranks reduction run end to end; with two ranks on
+one device the aggregate must come out at about the single-rank rate (the ranks share the HBM), which is the only scaling
+statement one GPU can make."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nproc, script_args, timeout=600):
+    env = dict(os.environ, GGQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    return proc
+
+
+def _bench(nproc, extra):
+    args = ["bench.py", "--gpus", str(nproc), "--steps", "6", "--warmup", "2", "--regions", "3", "--no-per-qtype", "--no-per-mode", "--cpu-seconds", "0",
+            "--no-workloads"] + extra
+    if nproc == 1:
+        proc = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+    else:
+        proc = _run(nproc, args)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]                     # rank 0 prints ONE JSON line, the other ranks nothing
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_pool_two_ranks_on_one_gpu():
+    one = _bench(1, ["--pairs", "16"])
+    two = _bench(2, ["--pairs", "16"])
+    for line in (one, two):
+        assert all(k in line for k in CONTRACT)
+        assert line["unit"] == "GB/s" and line["scaling"] == "weak" and line["higher_is_better"] is True and line["dtype"] == "f16"
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["bytes_per_step_per_gpu"] == one["config"]["bytes_per_step_per_gpu"]        # weak scaling: same pool per rank
+    assert len(two["config"]["timed_regions_ms_per_step"]) == 3
+    # two ranks time-share one device: each needs about twice as long per step, the aggregate stays at the device's rate
+    ratio = two["value"] / one["value"]
+    assert 0.85 <= ratio <= 1.10, (one["value"], two["value"])
+    assert 1.7 <= two["ms_per_step"] / one["ms_per_step"] <= 2.4
+
+
+@pytest.mark.timeout(900)
+def test_bench_sharded_weight_set_two_ranks_on_one_gpu(pkg):
+    one = _bench(1, ["--workload", "sd35-t5"])
+    two = _bench(2, ["--workload", "sd35-t5"])
+    assert one["scaling"] == two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert two["config"]["bytes_per_step"] == one["config"]["bytes_per_step"]                         # the SAME tensor list, sharded
+    assert 1.0 <= two["config"]["imbalance"] < 1.01
+    # disjoint cover, computed the way every rank computes it (no exchange)
+    manifest = pkg.manifests.sd35_t5("Q4_K_M")
+    parts = pkg.sharding.partition(manifest, 2)
+    assert sorted(i for p in parts for i in p) == list(range(len(manifest)))
+    assert 0.85 <= two["value"] / one["value"] <= 1.10, (one["value"], two["value"])
+
+
+@pytest.mark.timeout(600)
+def test_sharded_upload_from_two_processes(pkg, tmp_path):
+    from test_gpu_gguf import _mixed_file
+    path, spec, packed = _mixed_file(pkg, tmp_path)
+    out = tmp_path / "reports"
+    out.mkdir()
+    _run(2, [os.path.join("tests", "multirank_upload_worker.py"), path, str(out)])
+    reports = [json.load(open(out / f"rank{r}.json")) for r in range(2)]
+    assert reports[0] and reports[1] and not set(reports[0]) & set(reports[1])                       # every rank got work; disjoint
+    pre = "model.diffusion_model."
+    assert set(reports[0]) | set(reports[1]) == {n[len(pre):] for n, _, _ in spec} | {"bias"}         # together: the whole file
+    for rep in reports:
+        for k, ent in rep.items():
+            if pre + k not in packed:
+                continue
+            data = packed[pre + k]
+            assert ent["packed"] == hashlib.sha256(np.ascontiguousarray(data).tobytes()).hexdigest(), k
+            q = pkg.qtypes.Q(ent["qtype"])
+            assert ent["dense"] == hashlib.sha256(oracle.dequant_f16(q, data).view(np.uint16).tobytes()).hexdigest(), k

@@ -303,3 +303,22 @@ def test_torch_compile_through_reference_linear(mods, pkg, dev):
         except Exception as e:                                  # noqa: BLE001 -- Dynamo's support for this subclass is the reference's business
             pytest.skip(f"torch.compile cannot trace the reference's GGMLTensor on this torch: {type(e).__name__}")
     assert torch.equal(got, want)
+
+
+def test_cpu_route_for_load_time_tensors(mods, pkg, dev, monkeypatch):
+    """install(cpu_route_mb=...): a big CPU-resident quantized table (what loader.py:253-254,270,386,397 dequantize at load time) goes
+    host -> GPU -> host and comes back as the reference's CPU result, bit for bit; small ones and everything else keep the reference's path."""
+    rd, ro, Q = mods["dequant"], mods["ops"], pkg.qtypes.Q
+    big = H.ggml(ro, pkg.synth.make_tensor_bytes(Q.Q6_K, (4096, 1024), seed=1, mode="signed"), Q.Q6_K, (4096, 1024), "cpu", rows=4096)     # 3.4 MB packed
+    small = H.ggml(ro, pkg.synth.make_tensor_bytes(Q.Q6_K, (16, 1024), seed=2, mode="signed"), Q.Q6_K, (16, 1024), "cpu", rows=16)
+    want = {(id(t), dt, dd): rd.dequantize_tensor(t, dt, dd) for t in (big, small) for dt in (torch.float16, torch.float32) for dd in (None, torch.float32)}
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    with H.Installed(pkg, mods, cpu_route_mb=1):
+        for (tid, dt, dd), w in want.items():
+            t = big if tid == id(big) else small
+            got = rd.dequantize_tensor(t, dt, dd)
+            assert got.device.type == "cpu" and H.same_bits(got, w), (dt, dd)
+    assert counter.n == 4                                            # the four calls on the big table; the small one stayed on the CPU
+    with H.Installed(pkg, mods):                                     # option off: everything stays on the CPU
+        assert H.same_bits(rd.dequantize_tensor(big, torch.float16), want[(id(big), torch.float16, None)])
+    assert counter.n == 4

@@ -331,7 +331,7 @@ def test_reference_harness_dry_run_on_cpu(pkg, monkeypatch):
     conv, _ = H.make_conv2d(ro, pkg, Q.Q5_0, 16, 8, 4, 4, "cpu", seed=17)
     ids, img = torch.tensor([[0, 39, 7]]), torch.randn(2, 8, 12, 12)
     e0, c0 = emb(ids, out_dtype=torch.float32), conv(img)
-    for options in ({}, {"dense_cache_gb": 1}, {"fused_small_m": True}, {"gather_embedding": True}, {"overlap": True}, {"fused_mfma": True}):
+    for options in ({}, {"dense_cache_gb": 1}, {"fused_small_m": True}, {"gather_embedding": True}, {"overlap": True}, {"fused_mfma": True}, {"cpu_route_mb": 1}):
         with H.Installed(pkg, mods, **options):
             assert torch.equal(lin(x), want) and torch.equal(emb(ids, out_dtype=torch.float32), e0) and torch.equal(conv(img), c0)
     moved = plain.to("cpu")
