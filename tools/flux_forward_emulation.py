@@ -3,7 +3,7 @@
 run the way GGMLOps.Linear.forward does (reference ops.py:242-244) -- dequantize the weight, F.linear, drop it -- for one
 denoising step's worth of tokens, against the same F.linear calls on weights dequantized once up front.
 
-    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5] [--dense-cache-gb N] [--fused-small-m] [--overlap] [--lowvram]
+    python tools/flux_forward_emulation.py [--tokens 4608] [--dtype bfloat16] [--reps 5] [--dense-cache-gb N] [--fused-small-m] [--fused-mfma MAX_M] [--overlap] [--lowvram]
 
 Prints one JSON line: ms per emulated step with on-the-fly dequant, with resident dense weights, and the difference
 (the cost of the dequant path per step).  Layers run back to back on one stream; img/txt token counts are not modelled
@@ -32,11 +32,13 @@ def main():
     ap.add_argument("--mix", default="Q4_K_M")
     ap.add_argument("--dense-cache-gb", type=float, default=0.0, help="opt-in resident.DenseCache budget (0 = off, the reference's behaviour)")
     ap.add_argument("--fused-small-m", action="store_true", help="opt-in fused dequantize + linear for the 1-row (modulation) layers")
+    ap.add_argument("--fused-mfma", type=int, default=0, metavar="MAX_M", help="opt-in fused dequantize + GEMM on the matrix cores for inputs of up to MAX_M rows")
     ap.add_argument("--overlap", action="store_true", help="opt-in side-stream prefetch of the next layer's weight (overlap.LayerPrefetcher)")
     ap.add_argument("--lowvram", action="store_true", help="packed weights live on the CPU and are copied per layer per forward (ops.py:209)")
     args = ap.parse_args()
     pkg = load_package()
     pkg.ops.GGMLLinear.fuse_small_m = args.fused_small_m
+    pkg.ops.GGMLLinear.fuse_mfma_max_m = args.fused_mfma
     dev = torch.device("cuda:0")
     dtype = getattr(torch, args.dtype)
     manifest = pkg.manifests.flux_dev(args.mix)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-layer call latency of the hot path as ComfyUI drives it: one dequantize_tensor() per quantized
 layer per forward (reference ops.py:177), tensors of FLUX.1-dev shape B (3072x3072), rotating over a
-pool larger than the Infinity Cache.  Prints host-side us/call (enqueue cost) and end-to-end us/call."""
+pool larger than the Infinity Cache.  Prints host-side us/call (enqueue cost), end-to-end us/call of the eager loop (host-bound
+for the small shape: the GPU idles between kernels, each one starts cold) and `gpu_bound_us_per_call`: the same launches replayed
+from a captured HIP graph, back to back with no host in between -- what a layer's unpack costs inside a GPU-bound model step,
+where its ramp overlaps the previous kernel's drain."""
 import os
 import sys
 import time
@@ -40,8 +43,27 @@ def main():
             t_all = time.perf_counter() - t0
             n = reps * len(pool)
             nbytes = qt.algorithmic_bytes(q, 3072 * cols)
+            # GPU-bound: capture one pass over the pool into a graph (outputs are the graph's own buffers), replay it
+            side = torch.cuda.Stream()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                keep = [pkg.dequant.dequantize_tensor(t, dtype) for t in pool]          # warm the allocator on the capture stream
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph, stream=side):
+                    keep = [pkg.dequant.dequantize_tensor(t, dtype) for t in pool]
+            graph.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            t_graph = a.elapsed_time(b) * 1e-3
+            del graph, keep
             out[f"{qname}->{str(dtype).split('.')[-1]}"] = {"host_us_per_call": round(t_host / n * 1e6, 2), "e2e_us_per_call": round(t_all / n * 1e6, 2),
-                                                            "e2e_GBps": round(nbytes * n / t_all / 1e9, 1)}
+                                                            "e2e_GBps": round(nbytes * n / t_all / 1e9, 1),
+                                                            "gpu_bound_us_per_call": round(t_graph / n * 1e6, 2), "gpu_bound_GBps": round(nbytes * n / t_graph / 1e9, 1)}
     import json
     print(json.dumps(out))
 
