@@ -3,7 +3,12 @@
 table committed under profiles/: HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate passes),
 corrected as MI355X_MICROARCH.md prescribes and calibrated on the known-size streams of the same pass.
 
-    python tools/pmc_summarize.py gpurun_out/pmc > profiles/<name>.txt
+    python tools/pmc_summarize.py gpurun_out/pmc [--json profiles/pmc_traffic.json] > profiles/<name>.txt
+
+--json also writes the table bench.py reports ``roofline.traffic`` from: corrected bytes per launch per (format[, mode]) plus
+``_build_id`` = the identity of the kernel sources the counters were collected on (``_native.source_id()`` of THIS tree: the
+harness compiles the same csrc/ggq_capi.hip the library is built from), which bench.py compares with the loaded library's
+``ggq_build_id()`` before it reports a figure.
 """
 import collections
 import csv
@@ -31,7 +36,8 @@ ELEMENTS = 64 * (3072 * 3072 + 3072 * 12288)
 DT = {"0": "f16", "1": "bf16", "2": "f32"}
 
 
-def main(root):
+def main(root, json_out=None):
+    traffic = {}
     fetch = counters(f"{root}/p1/p_counter_collection.csv", "FETCH_SIZE")
     write = counters(f"{root}/p2/p_counter_collection.csv", "WRITE_SIZE")
     dur = durations(f"{root}/p1/p_kernel_trace.csv")
@@ -40,7 +46,7 @@ def main(root):
     print("# correction: read bytes = FETCH_SIZE * 2048 (gfx950 counts 16 B/lane streams at half rate; calibrated below on 1 GiB copies), write bytes = WRITE_SIZE * 1024")
     print(f"{'kernel (compute->out)':28s} {'FETCH_SIZE':>12s} {'WRITE_SIZE':>12s} {'read B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'write B':>14s} {'algorithmic':>14s} {'ratio':>7s} {'avg us':>9s}")
     for k in fetch:
-        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, -?\w+)*>", k)
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, (\d), \w+>", k)
         if m:
             fmt, out, comp = m.groups()
             name = f"{fmt} {DT[comp]}->{DT[out]}"
@@ -53,8 +59,23 @@ def main(root):
         else:
             continue
         rb, wb = fetch[k] * 2048, write.get(k, 0.0) * 1024
+        if m:
+            key = f"{fmt[3:]}:pairs64" + ("" if (comp, out) == ("0", "0") else f":{DT[comp]}->{DT[out]}")
+            traffic[key] = int(round(rb + wb))
         rr = f"{rb / a_read:7.4f}" if a_read else "    nan"
         print(f"{name:28s} {fetch[k]:12.1f} {write.get(k, 0.0):12.1f} {rb:14.0f} {a_read:14.0f} {rr} {wb:14.0f} {a_write:14.0f} {wb / a_write:7.4f} {dur.get(k, 0.0):9.1f}")
+    if json_out:
+        import json
+        import os
+        import importlib
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        nat = importlib.import_module("comfyui-gguf_amd._native")
+        traffic["_build_id"] = nat.source_id()
+        traffic["_provenance"] = ("tools/pmc_summarize.py over bash tests/microbench/pmc.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
+                                  "(--kernel-trace only); FETCH_SIZE x 2048 (gfx950 counts a 16 B/lane stream at half rate: calibrated on a 1 GiB copy in the same pass), "
+                                  "WRITE_SIZE x 1024; bytes per launch of the 64-pair FLUX pool, shipped kernels through ggq_plan_launch")
+        with open(json_out, "w") as f:
+            json.dump(traffic, f, indent=1)
     sq = f"{root}/p3/p_counter_collection.csv"
     names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
              "SQ_LDS_UNALIGNED_STALL", "GRBM_GUI_ACTIVE"]
@@ -65,7 +86,7 @@ def main(root):
     print("\n# SQ pass (per launch; SQ_* cycle counters are quad-cycles summed over waves)")
     print(f"{'kernel (compute->out)':28s} " + " ".join(f"{n:>22s}" for n in names))
     for k in cols["SQ_WAVES"]:
-        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, \w+, \w+, -?\d+, \d+, (\d)(?:, -?\w+)*>", k)
+        m = re.search(r"dequant_many<ggq::(Fmt\w+), \d+, (\d), \w+, \w+, \d+, (\d), \w+>", k)
         if not m:
             continue
         fmt, out, comp = m.groups()
@@ -73,4 +94,10 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
+    args = [a for a in sys.argv[1:]]
+    json_out = None
+    if "--json" in args:
+        i = args.index("--json")
+        json_out = args[i + 1]
+        del args[i:i + 2]
+    main(args[0] if args else "gpurun_out/pmc", json_out)
