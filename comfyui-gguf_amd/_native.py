@@ -101,12 +101,16 @@ class GGQNativeError(RuntimeError):
     """libggq_hip.so is missing / unloadable / returned a failing status."""
 
 
+DEQUANT_KERNEL_FILES = ("ggq_device.hpp", "ggq_capi.hip", "ggq_host.hpp")     # what the dequant kernels and their launch geometry are made of
+
+
 def source_id():
-    """First 16 hex digits of the sha256 over the compiler flags and every source / header of the library: what
+    """First 16 hex digits of the sha256 over the compiler flags and the sources of the DEQUANT kernels (device code + launch
+    geometry; not the GGUF reader or the fused-linear kernels, which do not touch what the PMC figures measure): what
     ``ggq_build_id()`` of an in-tree build returns (stamped with -DGGQ_BUILD_ID at compile time)."""
     import hashlib
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
-    for p in SOURCES + HEADERS:
+    for p in [os.path.join(CSRC, f) for f in DEQUANT_KERNEL_FILES]:
         with open(p, "rb") as f:
             h.update(os.path.basename(p).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -69,8 +69,8 @@ int ggq_last_hip_error(void);
 /* Library ABI version (bumped on any signature change). */
 int ggq_abi_version(void);
 
-/* Identity of the sources this binary was compiled from: the first 16 hex digits of the sha256 over the compiler flags and
- * every file under csrc/ + include/ (stamped by the build; "unstamped" for a hand build).  bench.py compares it with the id
+/* Identity of the dequant kernels this binary holds: the first 16 hex digits of the sha256 over the compiler flags and the
+ * sources of the dequant device code and its launch geometry (stamped by the build; "unstamped" for a hand build).  bench.py compares it with the id
  * recorded next to the committed PMC traffic figures, so a roofline.traffic number can never outlive the kernels it was
  * measured on. */
 const char* ggq_build_id(void);
