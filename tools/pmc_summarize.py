@@ -93,8 +93,33 @@ def main(root, json_out=None):
         print(f"{fmt + ' ' + DT[comp] + '->' + DT[out]:28s} " + " ".join(f"{cols[n].get(k, float('nan')):22.4g}" for n in names))
 
 
+def workloads(root, json_path):
+    """gpurun_out/pmcw/<workload>-<COUNTER>/ (tools/pmc_workloads.sh) -> "<workload>:Q4_K_M" entries of pmc_traffic.json: per plan launch
+    = the sum over the kernels of one step (one dequant_many per format present), mean over the steps of the run."""
+    import json
+    with open(json_path) as f:
+        table = json.load(f)
+    for w in ("flux", "sd35-t5"):
+        total = 0.0
+        for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+            per_kernel = collections.defaultdict(list)
+            for r in csv.DictReader(open(f"{root}/{w}-{counter}/p_counter_collection.csv")):
+                if r["Counter_Name"] == counter and "dequant_many" in r["Kernel_Name"]:
+                    per_kernel[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            step = sum(sum(v) / len(v) for v in per_kernel.values())          # every kernel runs once per step
+            print(f"{w:8s} {counter:10s} {len(per_kernel)} kernels/step  {step * scale / 1e6:12.2f} MB per step")
+            total += step * scale
+        table[f"{w}:Q4_K_M"] = int(round(total))
+    with open(json_path, "w") as f:
+        json.dump(table, f, indent=1)
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:]]
+    if "--workloads" in args:
+        i = args.index("--workloads")
+        workloads(args[i + 1], args[i + 2])
+        sys.exit(0)
     json_out = None
     if "--json" in args:
         i = args.index("--json")
