@@ -1,5 +1,5 @@
 import json, sys, os, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ggq_pkg import load_package
 pkg = load_package(); dev = torch.device("cuda:0"); q = pkg.qtypes.Q.Q4_K; bs, ts = pkg.qtypes.block_geometry(q)
 g = torch.Generator(device=dev).manual_seed(0)
@@ -24,10 +24,13 @@ def gpu_us(fn, pool, reps=60):
 rows_out = []
 for rows, cols in ((3072, 3072), (12288, 3072), (4096, 4096), (10240, 4096), (3072, 12288)):
     pool = pool_for(rows, cols, 12)
-    for m in (16, 48, 64, 96, 128, 192, 256, 384):
+    for m in (128, 256, 512, 1024):
         x = torch.randn(m, cols, device=dev, dtype=torch.bfloat16) * 0.05
         r = {"weight": f"{rows}x{cols}", "m": m}
         r["default"] = round(gpu_us(lambda w: torch.nn.functional.linear(x, pkg.dequant.dequantize_tensor(w, torch.bfloat16)), pool), 1)
-        for t in (32, 64, 128, 256):
+        dense = [pkg.dequant.dequantize_tensor(w, torch.bfloat16) for w in pool]
+        r["dense"] = round(gpu_us(lambda w: torch.nn.functional.linear(x, w), dense), 1)
+        del dense
+        for t in (64, 128, -64, -128, -256):
             r[f"t{t}"] = round(gpu_us(lambda w: pkg.fused.linear_mfma(x, w, tile_rows=t), pool), 1)
         rows_out.append(r); print(json.dumps(r), flush=True)
