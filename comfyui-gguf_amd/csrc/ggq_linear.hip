@@ -78,20 +78,10 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
-template <class F, int OUT, int MB>
-hipError_t launch_mfma_wide(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
-{
-    const dim3 grid((rows + (uint32_t)(MF_WAVES * 32) - 1u) / (uint32_t)(MF_WAVES * 32), (m + (uint32_t)(MB * 32) - 1u) / (uint32_t)(MB * 32));
-    hipLaunchKernelGGL((linear_mfma_wide<F, OUT, MB>), grid, dim3(MF_WAVES * 64), 0, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
-                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
-    return hipGetLastError();
-}
-
 constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4, 8
-struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES], wide[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][log2 MB]
+struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][log2 MB]
 #define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_mfma<F, OUT, 8>}
-#define GGQ_MFW_ROW(F, OUT) {launch_mfma_wide<F, OUT, 1>, launch_mfma_wide<F, OUT, 2>, launch_mfma_wide<F, OUT, 4>, launch_mfma_wide<F, OUT, 8>}
-#define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)}, {GGQ_MFW_ROW(F, OUT_F16), GGQ_MFW_ROW(F, OUT_BF16)} }
+#define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
     GGQ_MF(FmtQ2_K), GGQ_MF(FmtQ3_K), GGQ_MF(FmtQ4_K), GGQ_MF(FmtQ5_K), GGQ_MF(FmtQ6_K),
@@ -114,17 +104,11 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     // tile_rows: rows of x per workgroup tile (32, 64, 128, 256); 0 = pick from m.  Measured on FLUX / T5 layer shapes
     // (profiles/r02_mfma_linear_tile_sweep.txt): one 32-row block up to m = 32; 64-row tiles from there to m ~ 384 (two blocks share
     // every decoded weight, and twice as many workgroups as with 128-row tiles); 128-row tiles beyond.
-    // negative tile_rows = the WIDE variant (ggq_mfma.hpp: four neighbouring 32-column slices share one x tile) with |tile_rows| rows per tile
     int shape;
-    bool wide = false;
     if (tile_rows == 0) shape = m <= 32 ? 0 : (m < 384 ? 1 : 2);
-    else {
-        wide = tile_rows < 0;
-        const int t = wide ? -tile_rows : tile_rows;
-        if (t != 32 && t != 64 && t != 128 && t != 256) return GGQ_ERR_ARG;
-        shape = t == 32 ? 0 : (t == 64 ? 1 : (t == 128 ? 2 : 3));
-    }
-    const hipError_t err = (wide ? e->wide : e->fn)[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
+    else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
+    else return GGQ_ERR_ARG;
+    const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
     return err == hipSuccess ? GGQ_OK : hip_fail(err);
 }
 

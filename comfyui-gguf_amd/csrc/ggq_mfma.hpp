@@ -62,9 +62,13 @@ template <class F> struct MfmaGeom {
 // (32 B of each 128-B line per instruction) overflows the L1 -- 4 waves x MB x 4 KiB per step -- and every line is fetched from L2
 // several times (measured: a 128-row tile ran 2.5x SLOWER than four 32-row tiles).  So for MB >= 2 the wave first copies a
 // (MB*32 rows x 32 elements) piece of x into its own LDS slice with coalesced 16 B/lane loads (4 lanes per row: whole 64-B
-// sectors, each fetched once; the next piece is already in flight in registers) and reads the fragments back with ds_read_b128;
-// rows are 80 bytes apart in LDS, so the 16 lanes of a read phase hit 16 different 16-byte bank groups.
-constexpr int MF_XPITCH = 80;
+// sectors, each fetched once; the next TWO pieces are already in flight in registers) and reads the fragments back with ds_read_b128.
+// LDS layout of a piece: 64 bytes per row, the 16-byte column XOR-swizzled by ((row >> 1) ^ (row >> 3)) & 3 -- conflict-free both for the
+// writes (4 lanes per row, 16 rows per instruction) and for the fragment reads (one row per lane), whether the LDS serves 8, 16 or 32 lanes
+// per phase.  (The first version padded rows to 80 bytes instead: rocprof counted SQ_LDS_BANK_CONFLICT = 33 % of its LDS cycles, and with
+// one piece in flight 45 % of wave cycles sat in s_waitcnt -- profiles/r02_mfma_kernel_counters.txt.)
+constexpr int MF_XPITCH = 64;
+GGQ_DEV uint32_t mf_swz(uint32_t row) { return ((row >> 1) ^ (row >> 3)) & 3u; }
 
 template <class F, int OUT, int MB>
 __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
@@ -155,17 +159,25 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
         constexpr int NX = MB * 2;
         const int lrow = lane >> 2, lpc = lane & 3;
         const GGQ_GLOBAL uint8_t* xsrc[NX];
+        uint32_t xdst[NX];
 #pragma unroll
         for (int i = 0; i < NX; i++) {
-            const uint32_t mr = m0 + (uint32_t)(lrow + 16 * i);
+            const uint32_t row = (uint32_t)(lrow + 16 * i), mr = m0 + row;
             xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(lpc * 16);
+            xdst[i] = row * (uint32_t)MF_XPITCH + (((uint32_t)lpc ^ mf_swz(row)) * 16u);
         }
-        u32x4 xr[NX];
-        auto xfetch = [&](uint32_t kb) {
+        const uint32_t swr = mf_swz((uint32_t)r);                                  // rows 32 mb + r swizzle like row r
+        u32x4 ring[2][NX];                                                         // pieces g and g+1 in flight while piece g-1 is consumed
+        auto xfetch = [&](uint32_t piece, u32x4 (&dst)[NX]) {                      // piece = index over the wave's own sequence of 32-element pieces
+            // the wave's p-th piece: span = wave + 4 (p / 8), t = p % 8
+            const uint32_t kb = (((uint32_t)wave + MF_WAVES * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
 #pragma unroll
-            for (int i = 0; i < NX; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
+            for (int i = 0; i < NX; i++) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
         };
-        if ((uint32_t)wave < n_spans) xfetch((uint32_t)wave * (uint32_t)(MF_SPAN * 2));
+        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + MF_WAVES - 1) / MF_WAVES : 0u, my_pieces = my_spans * 8u;
+        if (my_pieces > 0) xfetch(0u, ring[0]);
+        if (my_pieces > 1) xfetch(1u, ring[1]);
+        uint32_t piece = 0;
         for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
 #pragma unroll
             for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
@@ -173,19 +185,18 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
-            const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
 #pragma unroll
-            for (int t = 0; t < 8; t++) {                                          // 32 contraction elements per t: k = 32 t + 16 h + 8 s .. + 7
+            for (int t = 0; t < 8; t++, piece++) {                                 // 32 contraction elements per t: k = 32 t + 16 h + 8 s .. + 7
 #pragma unroll
-                for (int i = 0; i < NX; i++) *reinterpret_cast<u32x4*>(xs + (lrow + 16 * i) * MF_XPITCH + lpc * 16) = xr[i];
+                for (int i = 0; i < NX; i++) *reinterpret_cast<u32x4*>(xs + xdst[i]) = ring[t & 1][i];
                 wave_sync();
-                if (t < 7) xfetch(kbyte + (uint32_t)((t + 1) * 64));
-                else if (span + MF_WAVES < n_spans) xfetch((span + MF_WAVES) * (uint32_t)(MF_SPAN * 2));
+                if (piece + 2 < my_pieces) xfetch(piece + 2, ring[t & 1]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
                     u32x4 xa[MB];
+                    const uint32_t col = (((uint32_t)(2 * h + s2)) ^ swr) * 16u;
 #pragma unroll
-                    for (int mb = 0; mb < MB; mb++) xa[mb] = *reinterpret_cast<const u32x4*>(xs + (mb * 32 + r) * MF_XPITCH + h * 32 + s2 * 16);
+                    for (int mb = 0; mb < MB; mb++) xa[mb] = *reinterpret_cast<const u32x4*>(xs + (mb * 32 + r) * MF_XPITCH + col);
                     step(wspan, 4 * t + 2 * h + s2, xa);
                 }
                 wave_sync();                                                       // xs is rewritten at the top of the t loop
@@ -228,146 +239,6 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             }
         }
     }
-}
-
-// ---- the WIDE variant: for a few hundred rows of x and more.
-// The kernel above gives every 32-column slice of W its own workgroup and lets the four waves split K; each wave then fetches its OWN
-// pieces of x, MB*2 loads per thread per 32 elements of k, issued only one step ahead (registers), so at 128+ rows a wave spends most of
-// its time waiting for x (rocprof SQ counters: 45 % of wave cycles in s_waitcnt, MFMA pipes 16 % busy), and every slice re-reads the same
-// x from L2.  Here the four waves take four NEIGHBOURING 32-column slices and walk K together: one x tile per workgroup per step, loaded
-// by all 256 threads (MB/2 loads per thread), FOUR steps ahead in a register ring, double-buffered in LDS behind one s_barrier per step, and
-// read as MFMA fragments by all four waves -- a quarter of the x traffic, prefetch depth 4 instead of 1, no cross-wave reduction at the end
-// (each wave owns its 32 output columns outright).  The LDS tile is 64 bytes per row with the 16-byte column XOR-swizzled by
-// ((row >> 1) ^ (row >> 3)) & 3, which makes the coalesced writes (4 lanes per row) AND the fragment reads (one row per lane) bank-conflict
-// free (the kernel above measured SQ_LDS_BANK_CONFLICT = 33 % of its LDS cycles with a padded pitch).
-template <class F, int OUT, int MB>
-__global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma_wide(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
-                                                                  const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
-                                                                  uint32_t m, uint32_t n_rows, uint32_t cols)
-{
-    using G = MfmaGeom<F>;
-    static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only");
-    constexpr int CPB = F::BS / 8;
-    constexpr int XROWS = MB * 32;
-    constexpr int STAGE = XROWS * 64;                                              // one x tile: XROWS rows x 32 elements
-    constexpr int NXL = (XROWS * 4 + MF_WAVES * 64 - 1) / (MF_WAVES * 64);         // 16-byte loads per thread per tile
-    __shared__ __attribute__((aligned(16))) uint8_t smem[MF_WAVES * G::SLICE + 2 * STAGE];
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = (int)(threadIdx.x & 63);
-    const int r = lane & 31, h = lane >> 5;
-    const uint32_t n0 = blockIdx.x * (uint32_t)(MF_WAVES * 32) + (uint32_t)(wave * 32), m0 = blockIdx.y * (uint32_t)XROWS;
-    const gcptr packed = (gcptr)packed_;
-    const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
-    const uint32_t n_spans = cols / MF_SPAN, n_steps = cols / 32;
-    uint8_t* slice = smem + wave * G::SLICE;
-    uint8_t* xst = smem + MF_WAVES * G::SLICE;
-
-    const uint32_t wrow = (n0 + (uint32_t)r < n_rows) ? n0 + (uint32_t)r : n_rows - 1;
-    const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
-    const uint32_t nclamp = n_rows - 1;
-
-    auto fetch = [&](uint32_t span, u32x4 (&pf)[G::NUW]) {
-#pragma unroll
-        for (int u = 0; u < G::NUW; u++) {
-            const uint32_t unit = (uint32_t)(lane + 64 * u), ur = unit / (uint32_t)G::U, uu = unit % (uint32_t)G::U;
-            const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : nclamp;
-            const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
-            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
-            pf[u] = (ur < 32u && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
-        }
-    };
-
-    // the x tile: thread -> 16-byte units tid + 256 i: row = unit / 4, piece = unit % 4
-    const GGQ_GLOBAL uint8_t* xsrc[NXL];
-    uint32_t xdst[NXL];
-    bool xon[NXL];
-#pragma unroll
-    for (int i = 0; i < NXL; i++) {
-        const uint32_t unit = threadIdx.x + (uint32_t)(MF_WAVES * 64 * i), row = unit >> 2, pc = unit & 3u;
-        xon[i] = row < (uint32_t)XROWS;
-        const uint32_t mr = m0 + (xon[i] ? row : 0u);
-        xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + pc * 16u;
-        xdst[i] = row * 64u + ((pc ^ (((row >> 1) ^ (row >> 3)) & 3u)) * 16u);
-    }
-    u32x4 ring[4][NXL];
-    auto xfetch = [&](uint32_t step, u32x4 (&dst)[NXL]) {
-#pragma unroll
-        for (int i = 0; i < NXL; i++)
-            if (xon[i]) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * 64u);
-    };
-    auto xstore = [&](int stage, const u32x4 (&src)[NXL]) {
-#pragma unroll
-        for (int i = 0; i < NXL; i++)
-            if (xon[i]) *reinterpret_cast<u32x4*>(xst + stage * STAGE + xdst[i]) = src[i];
-    };
-    const uint32_t swr = (uint32_t)(((r >> 1) ^ (r >> 3)) & 3);                     // swizzle of this lane's fragment rows (32 mb + r)
-
-    f32x16 acc[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[mb][i] = 0.0f;
-
-    u32x4 pf[G::NUW];
-    fetch(0u, pf);
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if ((uint32_t)k < n_steps) xfetch((uint32_t)k, ring[k]);
-    xstore(0, ring[0]);
-    __syncthreads();
-
-    for (uint32_t span = 0; span < n_spans; span++) {
-#pragma unroll
-        for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
-        wave_sync();
-        if (span + 1 < n_spans) fetch(span + 1, pf);
-        const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
-        const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
-#pragma unroll
-        for (int t = 0; t < 8; t++) {                                              // step g = 8 span + t: k = 32 g + 16 h + 8 s .. + 7
-            const uint32_t g = span * 8u + (uint32_t)t;
-            if (g + 1 < n_steps) xstore((t + 1) & 1, ring[(t + 1) & 3]);           // tile g+1 -> the other stage (its readers passed the last barrier)
-            if (g + 4 < n_steps) xfetch(g + 4, ring[t & 3]);                       // tile g+4 takes the registers tile g left
-            const uint8_t* xt = xst + (t & 1) * STAGE;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                const int j = 4 * t + 2 * h + s2;
-                const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, j % CPB);
-                uint32_t w[4];
-                weights8<F, OUT>(f, w);
-                const u32x4 wb{w[0], w[1], w[2], w[3]};
-                const uint32_t col = (((uint32_t)(2 * h + s2)) ^ swr) * 16u;
-#pragma unroll
-                for (int mb = 0; mb < MB; mb++) {
-                    const u32x4 xa = *reinterpret_cast<const u32x4*>(xt + (mb * 32 + r) * 64 + col);
-                    acc[mb] = mfma32<OUT>(xa, wb, acc[mb]);
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    float bias = 0.0f;
-    const uint32_t ncol = n0 + (uint32_t)r;
-    if (bias_ != nullptr && ncol < n_rows) {
-        const uint16_t b = *reinterpret_cast<const uint16_t*>(bias_ + (size_t)ncol * 2);
-        if constexpr (OUT == OUT_F16) bias = (float)__builtin_bit_cast(_Float16, b);
-        else bias = bits_f32((uint32_t)b << 16);
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; mb++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint32_t mr = m0 + (uint32_t)(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
-            if (mr < m && ncol < n_rows) {
-                const float v = acc[mb][i] + bias;
-                uint16_t o;
-                if constexpr (OUT == OUT_F16) o = __builtin_bit_cast(uint16_t, (_Float16)v);
-                else o = (uint16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
-                *reinterpret_cast<uint16_t*>(y_ + ((size_t)mr * n_rows + ncol) * 2) = o;
-            }
-        }
 }
 
 }  // namespace ggq
