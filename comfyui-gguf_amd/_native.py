@@ -18,9 +18,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "_lib")
 # GGQ_HIP_LIB: load another build of the library (A/B measurements); default = the in-tree build
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
-SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip")]
+SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -76,7 +76,8 @@ SYMBOLS = {
     "ggq_plan_destroy": (None, [_vp]),
     "ggq_linear_small": (_int, [_int, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _int, _vp]),
     "ggq_overlap_create": (_int, [_int, ctypes.POINTER(_vp)]),
-    "ggq_overlap_prefetch": (_int, [_vp, _int, _int, _vp, _vp, _u64, _u64, _vp, _int, _int, _vp]),
+    "ggq_overlap_copy": (_int, [_vp, _int, _vp, _vp, _u64]),
+    "ggq_overlap_prefetch": (_int, [_vp, _int, _int, _int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_overlap_wait": (_int, [_vp, _int, _vp]),
     "ggq_overlap_destroy": (None, [_vp]),
     "ggq_linear_mfma": (_int, [_int, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _int, _int, _vp]),

@@ -321,7 +321,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 7; }
+int ggq_abi_version(void) { return 8; }
 
 #ifndef GGQ_BUILD_ID
 #define GGQ_BUILD_ID "unstamped"
@@ -472,74 +472,6 @@ void ggq_plan_destroy(ggq_plan* plan)
     if (plan->dev_coarse) (void)hipFree(plan->dev_coarse);
     if (plan->dev_table) (void)hipFree(plan->dev_table);
     delete plan;
-}
-
-// ---- side-stream prefetch (include/ggq.h "layer i+1 while layer i computes")
-struct ggq_overlap {
-    int device = 0, n_slots = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t main_mark[16] = {}, done[16] = {};
-};
-
-int ggq_overlap_create(int n_slots, ggq_overlap** out)
-{
-    if (!out || n_slots < 1 || n_slots > 16) return GGQ_ERR_ARG;
-    *out = nullptr;
-    ggq_overlap* ov = new (std::nothrow) ggq_overlap();
-    if (!ov) return GGQ_ERR_NOMEM;
-    ov->n_slots = n_slots;
-    hipError_t e = hipGetDevice(&ov->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ov->side, hipStreamNonBlocking);
-    for (int i = 0; i < n_slots && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&ov->main_mark[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ov->done[i], hipEventDisableTiming);
-    }
-    if (e != hipSuccess) {
-        ggq_overlap_destroy(ov);
-        return hip_fail(e);
-    }
-    *out = ov;
-    return GGQ_OK;
-}
-
-int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int qtype, const void* host_packed, void* dev_packed, uint64_t packed_bytes,
-                         uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* main_stream)
-{
-    if (!ov || slot < 0 || slot >= ov->n_slots) return GGQ_ERR_ARG;
-    const FormatEntry* f = find_format(qtype);
-    const int rc = check_tensor(f, dev_packed, out, n_blocks, compute_dtype, out_dtype);
-    if (rc != GGQ_OK) return rc;
-    if (host_packed && packed_bytes < n_blocks * (uint64_t)f->type_size) return GGQ_ERR_ARG;
-    hipError_t e = hipEventRecord(ov->main_mark[slot], static_cast<hipStream_t>(main_stream));
-    if (e == hipSuccess) e = hipStreamWaitEvent(ov->side, ov->main_mark[slot], 0);
-    if (e == hipSuccess && host_packed && packed_bytes) e = hipMemcpyAsync(dev_packed, host_packed, (size_t)packed_bytes, hipMemcpyHostToDevice, ov->side);
-    if (e == hipSuccess && n_blocks) {
-        const Desc d{static_cast<const uint8_t*>(dev_packed), static_cast<uint8_t*>(out), n_blocks, 0};
-        e = f->one[compute_dtype][out_dtype](d, ov->side);
-    }
-    if (e == hipSuccess) e = hipEventRecord(ov->done[slot], ov->side);
-    return e == hipSuccess ? GGQ_OK : hip_fail(e);
-}
-
-int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream)
-{
-    if (!ov || slot < 0 || slot >= ov->n_slots) return GGQ_ERR_ARG;
-    const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), ov->done[slot], 0);
-    return e == hipSuccess ? GGQ_OK : hip_fail(e);
-}
-
-void ggq_overlap_destroy(ggq_overlap* ov)
-{
-    if (!ov) return;
-    if (ov->side) {
-        (void)hipStreamSynchronize(ov->side);
-        (void)hipStreamDestroy(ov->side);
-    }
-    for (int i = 0; i < 16; i++) {
-        if (ov->main_mark[i]) (void)hipEventDestroy(ov->main_mark[i]);
-        if (ov->done[i]) (void)hipEventDestroy(ov->done[i]);
-    }
-    delete ov;
 }
 
 }  // extern "C"

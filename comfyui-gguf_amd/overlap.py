@@ -8,8 +8,10 @@ The reference's ``GGMLLayer.cast_bias_weight`` (ops.py:194-211) does, per layer 
 
 Three different resources, used strictly one after the other.  ``LayerPrefetcher`` learns the order in which layers are called
 (module A is followed by module B -- it repeats every denoising step) and, when A is called, enqueues B's copy + unpack on a
-SIDE stream into one of two persistent scratch buffers (include/ggq.h ``ggq_overlap_*``: event-ordered after everything the main
-stream holds, so the buffer's previous consumer is done).  When B is called its dense weight is already there (or on its way: the
+side streams (include/ggq.h ``ggq_overlap_*``): the unpack into one of two persistent dense scratch buffers, event-ordered after
+everything the main stream holds (so the buffer's previous consumer is done); in low-VRAM mode the host->device copies on a stream of
+their own, TWO layers ahead into three staging buffers, gated only by the unpack that last read the staging buffer -- the PCIe link
+never waits for the GEMMs.  When B is called its dense weight is already there (or on its way: the
 main stream waits on the event, never the host).  The values are the very same kernels' output: results stay bit-identical.
 
 Measured (tools/flux_forward_emulation.py, FLUX.1-dev, 4608 tokens, bf16; profiles/r02_flux_forward_emulation_overlap.json):
@@ -22,7 +24,8 @@ What it changes for the caller, and why it is opt-in (``install(..., overlap=Tru
     ``cast_bias_weight`` would;
   * low-VRAM mode keeps a PINNED host copy of every packed weight it has seen (the async copy needs page-locked memory): host RAM
     of the size of the packed model (6.8 GB for FLUX.1-dev Q4_K_M);
-  * 2 x the largest dense weight of scratch per device (2 x 132 MB for FLUX.1-dev in bf16).
+  * 2 x the largest dense weight of scratch per device (2 x 132 MB for FLUX.1-dev in bf16), plus 3 x the largest packed weight of
+    staging in low-VRAM mode (3 x 37 MB).
 LoRA-patched weights (patched in place, ops.py:183-190), non-quantized weights, dtypes the kernels do not emit, tracing under
 torch.compile and stream capture all take the reference's path untouched; a mispredicted order only costs the prefetch.
 """
@@ -36,16 +39,24 @@ import torch
 from . import _native
 from . import dequant as _dq
 
-N_SLOTS = 2
+N_SLOTS = 2               # dense scratch slots: the weight being consumed and the one being unpacked
+N_STAGING = 3             # packed staging slots (low-VRAM mode): being unpacked, copied for the next layer, copied for the one after
 
 
 class _Slot:
-    __slots__ = ("dense", "packed", "owner")
+    __slots__ = ("dense", "owner")
 
     def __init__(self):
         self.dense = None         # uint8 scratch on the device, grown to the largest dense weight seen
-        self.packed = None        # uint8 staging for packed bytes copied from the host (low-VRAM mode)
         self.owner = None         # id(module) whose prefetched weight currently lives here
+
+
+class _Staging:
+    __slots__ = ("packed", "owner")
+
+    def __init__(self):
+        self.packed = None        # uint8 staging for packed bytes copied from the host
+        self.owner = None         # (id(module), weight version) whose packed bytes were last copied here
 
 
 class _Device:
@@ -53,9 +64,11 @@ class _Device:
         self.index = index
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(index):
-            _native.check(_native.lib().ggq_overlap_create(N_SLOTS, ctypes.byref(self.handle)), "ggq_overlap_create")
+            _native.check(_native.lib().ggq_overlap_create(max(N_SLOTS, N_STAGING), ctypes.byref(self.handle)), "ggq_overlap_create")
         self.slots = [_Slot() for _ in range(N_SLOTS)]
+        self.staging = [_Staging() for _ in range(N_STAGING)]
         self.turn = 0
+        self.staging_turn = 0
 
     def close(self):
         if self.handle:
@@ -133,10 +146,40 @@ class LayerPrefetcher:
         self._pinned[id(module)] = (weakref.ref(w), w._version, pinned)
         return pinned
 
+    def _stage_copy(self, module, index):
+        """Low-VRAM mode: enqueue the host -> device copy of module's packed weight on the COPY stream (not ordered against the main
+        stream: it runs as far ahead as there are staging slots).  Returns the staging slot index, or None."""
+        w = getattr(module, "weight", None)
+        if w is None or getattr(w, "patches", None):
+            return None
+        with _dq._NoTorchFunction():
+            if w.is_cuda:
+                return None
+            host = self._host_bytes(module, w)
+        dev = self._dev(index)
+        tag = (id(module), w._version)
+        for si, st in enumerate(dev.staging):
+            if st.owner == tag:
+                return si                                     # already on its way (scheduled two layers ahead)
+        si = dev.staging_turn
+        st = dev.staging[si]
+        nbytes = host.numel()
+        if st.packed is None or st.packed.numel() < nbytes:
+            torch.cuda.synchronize(index)                     # growing a buffer frees the old one: nothing may still be using it
+            with torch.cuda.device(index):
+                st.packed = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{index}")
+        with torch.cuda.device(index):
+            rc = _native.lib().ggq_overlap_copy(dev.handle, si, host.data_ptr(), st.packed.data_ptr(), nbytes)
+        _native.check(rc, "ggq_overlap_copy")
+        st.owner = tag
+        dev.staging_turn = (si + 1) % N_STAGING
+        return si
+
     def _schedule(self, module, dtype, index, main_stream, avoid_slot=None):
-        """Enqueue module's (copy +) unpack on the side stream of device `index`.  Returns False if it cannot be prefetched.
-        ``avoid_slot``: the slot whose weight is being handed out by THIS call -- its consumer is not enqueued yet, so the
-        event recorded now would not cover it (in the learnt order the rotation never picks it; after a reordering it can)."""
+        """Enqueue module's unpack (after its copy, in low-VRAM mode) on the unpack stream of device `index`.  Returns False if it
+        cannot be prefetched.  ``avoid_slot``: the dense slot whose weight is being handed out by THIS call -- its consumer is not
+        enqueued yet, so the event recorded now would not cover it (in the learnt order the rotation never picks it; after a reordering
+        it can)."""
         w = module.weight
         qtype = getattr(w, "tensor_type", None)
         ent = _dq._HIP_TABLE.get(qtype) or _dq._HIP_TABLE.get(_dq._qtype_key(qtype))
@@ -156,9 +199,13 @@ class LayerPrefetcher:
         with _dq._NoTorchFunction():
             on_host = not w.is_cuda
             if on_host:
-                host = self._host_bytes(module, w)
-                nbytes = host.numel()
+                staging_index = self._stage_copy(module, index)
+                if staging_index is None:
+                    return False
+                data = dev.staging[staging_index].packed
+                nbytes = self._pinned[id(module)][2].numel()
             else:
+                staging_index = -1
                 if w.device.index != index:
                     return False
                 data = w
@@ -174,34 +221,21 @@ class LayerPrefetcher:
             if numel != n or n == 0:
                 return False
             dense_bytes = n * (4 if dtype is torch.float32 else 2)
-            if slot.dense is None or slot.dense.numel() < dense_bytes or (on_host and (slot.packed is None or slot.packed.numel() < nbytes)):
-                # growing a buffer frees the old one: nothing on either stream may still be using it
-                torch.cuda.synchronize(index)
+            if slot.dense is None or slot.dense.numel() < dense_bytes:
+                torch.cuda.synchronize(index)             # growing a buffer frees the old one: nothing on any stream may still be using it
                 with torch.cuda.device(index):
-                    if slot.dense is None or slot.dense.numel() < dense_bytes:
-                        slot.dense = torch.empty(dense_bytes, dtype=torch.uint8, device=f"cuda:{index}")
-                    if on_host and (slot.packed is None or slot.packed.numel() < nbytes):
-                        slot.packed = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{index}")
+                    slot.dense = torch.empty(dense_bytes, dtype=torch.uint8, device=f"cuda:{index}")
             dense = slot.dense[:dense_bytes].view(dtype).view(shape)
             if slot.owner is not None:
                 self._pending.pop(slot.owner, None)       # whatever lived in this slot is about to be overwritten
-            if _dq._cur_device() != index:
-                with torch.cuda.device(index):
-                    rc = self._prefetch_call(dev, slot_index, qid, host if on_host else None, slot.packed if on_host else data, nbytes, n_blocks,
-                                             dense, compute_code, dtype, main_stream)
-            else:
-                rc = self._prefetch_call(dev, slot_index, qid, host if on_host else None, slot.packed if on_host else data, nbytes, n_blocks,
-                                         dense, compute_code, dtype, main_stream)
+            with torch.cuda.device(index):
+                rc = _native.lib().ggq_overlap_prefetch(dev.handle, slot_index, staging_index, qid, data.data_ptr(), n_blocks, dense.data_ptr(),
+                                                        compute_code, _dq._OUT_CODE[dtype], main_stream)
         _native.check(rc, "ggq_overlap_prefetch")
         slot.owner = id(module)
         dev.turn = (slot_index + 1) % N_SLOTS
         self._pending[id(module)] = (weakref.ref(w), w._version, dtype, compute, index, slot_index, dense)
         return True
-
-    @staticmethod
-    def _prefetch_call(dev, slot_index, qid, host, dev_packed, nbytes, n_blocks, dense, compute_code, dtype, main_stream):
-        return _native.lib().ggq_overlap_prefetch(dev.handle, slot_index, qid, None if host is None else host.data_ptr(), dev_packed.data_ptr(), nbytes,
-                                                  n_blocks, dense.data_ptr(), compute_code, _dq._OUT_CODE[dtype], main_stream)
 
     # ---- the call
     def weight_for(self, module, dtype, device, compute_now):
@@ -235,17 +269,23 @@ class LayerPrefetcher:
         self._last[key] = (dtype, index)
         nref = self._next.get(key)
         nxt = nref() if nref is not None else None
-        if nxt is not None and id(nxt) not in self._pending:
-            last = self._last.get(id(nxt))
-            if last is not None and last[1] == index:
-                self._schedule(nxt, last[0], index, main_stream, avoid_slot=used_slot)
+        if nxt is not None:
+            if id(nxt) not in self._pending:
+                last = self._last.get(id(nxt))
+                if last is not None and last[1] == index:
+                    self._schedule(nxt, last[0], index, main_stream, avoid_slot=used_slot)
+            # low-VRAM mode: the layer after the next one starts its PCIe copy now, so the link never idles behind the unpack
+            n2ref = self._next.get(id(nxt))
+            nxt2 = n2ref() if n2ref is not None else None
+            if nxt2 is not None and nxt2 is not module and id(nxt2) in self._last:
+                self._stage_copy(nxt2, index)
         return dense
 
     def stats(self):
         return {"hits": self.hits, "misses": self.misses, "mispredicted": self.mispredicted, "bypassed": self.bypassed,
                 "pinned_host_bytes": sum(e[2].numel() for e in self._pinned.values()),
-                "scratch_bytes": sum((s.dense.numel() if s.dense is not None else 0) + (s.packed.numel() if s.packed is not None else 0)
-                                     for d in self._devices.values() for s in d.slots)}
+                "scratch_bytes": sum(sum(s.dense.numel() for s in d.slots if s.dense is not None) + sum(s.packed.numel() for s in d.staging if s.packed is not None)
+                                     for d in self._devices.values())}
 
     def close(self):
         for index in list(self._devices):

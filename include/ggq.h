@@ -136,19 +136,24 @@ void ggq_plan_destroy(ggq_plan* plan);
 
 /* The reference dequantizes a layer's weight and then runs its GEMM, one after the other on one stream (ops.py:242-244), and in
  * low-VRAM mode first copies the packed bytes host->device on that same stream (ops.py:209).  The unpack is HBM-bound, the copy
- * PCIe-bound, the GEMM MFMA-bound: a ggq_overlap owns a side stream (and per-slot events) on which the NEXT layer's copy + unpack
- * run while the current layer's GEMM occupies the matrix cores.  Values are the same kernels' output: bit-identical.
- *   ggq_overlap_create     side stream + 2 events per slot on the current device; n_slots in [1, 16].
- *   ggq_overlap_prefetch   enqueue on the side stream, ordered after everything `main_stream` holds at this moment (so a slot's
- *                          previous consumer has finished): [if host_packed != NULL: copy packed_bytes host_packed -> dev_packed]
- *                          then ggq_dequant(qtype, dev_packed, n_blocks, out, compute_dtype, out_dtype).  host_packed should be
- *                          pinned memory (a pageable source makes the copy synchronous for the calling thread).
- *   ggq_overlap_wait       make `main_stream` wait for the slot's last prefetch (no host sync).
+ * PCIe-bound, the GEMM MFMA-bound: a ggq_overlap owns a COPY stream and an UNPACK stream (and per-slot events) on which the next
+ * layers' copies and the NEXT layer's unpack run while the current layer's GEMM occupies the matrix cores.  Values are the same
+ * kernels' output: bit-identical.  Slots are the caller's buffers; the object only orders the work on them:
+ *   ggq_overlap_create     two streams + 4 events per slot on the current device; n_slots in [1, 16] (dense slots and staging slots
+ *                          are numbered independently, both < n_slots).
+ *   ggq_overlap_copy       enqueue on the copy stream: packed_bytes host_packed -> dev_packed (staging slot `staging_slot`), after
+ *                          the unpack that last read that staging slot.  Not ordered against the caller's stream at all: copies run
+ *                          as far ahead as there are staging slots.  host_packed should be pinned memory.
+ *   ggq_overlap_prefetch   enqueue on the unpack stream, ordered after everything `main_stream` holds at this moment (so the dense
+ *                          slot's previous consumer has finished) and, if staging_slot >= 0, after that slot's copy:
+ *                          ggq_dequant(qtype, dev_packed, n_blocks, out, compute_dtype, out_dtype).
+ *   ggq_overlap_wait       make `main_stream` wait for the dense slot's last prefetch (no host sync).
  * The caller owns every buffer and keeps it alive until the consumer has run; one thread drives a ggq_overlap at a time. */
 typedef struct ggq_overlap ggq_overlap;
 int ggq_overlap_create(int n_slots, ggq_overlap** out);
-int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int qtype, const void* host_packed, void* dev_packed, uint64_t packed_bytes,
-                         uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* main_stream);
+int ggq_overlap_copy(ggq_overlap* ov, int staging_slot, const void* host_packed, void* dev_packed, uint64_t packed_bytes);
+int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int staging_slot, int qtype, const void* dev_packed, uint64_t n_blocks, void* out,
+                         int compute_dtype, int out_dtype, void* main_stream);
 int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream);
 void ggq_overlap_destroy(ggq_overlap* ov);
 

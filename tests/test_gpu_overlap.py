@@ -156,21 +156,37 @@ def test_c_abi_argument_checks(pkg):
     lib = nat.lib()
     h = ctypes.c_void_p()
     assert lib.ggq_overlap_create(0, ctypes.byref(h)) == nat.GGQ_ERR_ARG and lib.ggq_overlap_create(17, ctypes.byref(h)) == nat.GGQ_ERR_ARG
-    assert lib.ggq_overlap_create(2, ctypes.byref(h)) == nat.GGQ_OK and h.value
+    assert lib.ggq_overlap_create(3, ctypes.byref(h)) == nat.GGQ_OK and h.value
     q4k = int(pkg.qtypes.Q.Q4_K)
-    assert lib.ggq_overlap_prefetch(h, 2, q4k, None, 16, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG       # slot out of range
-    assert lib.ggq_overlap_prefetch(h, 0, 99, None, 16, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_QTYPE
-    assert lib.ggq_overlap_prefetch(h, 0, q4k, None, 24, 0, 1, 16, 0, 0, None) == nat.GGQ_ERR_ALIGN
-    assert lib.ggq_overlap_prefetch(h, 0, q4k, 4096, 16, 100, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG    # host copy shorter than the blocks
+    s = torch.cuda.current_stream(DEV).cuda_stream
+    # (handle, dense slot, staging slot or -1, qtype, packed, n_blocks, out, compute, out dtype, main stream)
+    assert lib.ggq_overlap_prefetch(h, 3, -1, q4k, 16, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG        # dense slot out of range
+    assert lib.ggq_overlap_prefetch(h, 0, 3, q4k, 16, 1, 16, 0, 0, None) == nat.GGQ_ERR_ARG         # staging slot out of range
+    assert lib.ggq_overlap_prefetch(h, 0, -1, 99, 16, 1, 16, 0, 0, None) == nat.GGQ_ERR_QTYPE
+    assert lib.ggq_overlap_prefetch(h, 0, -1, q4k, 24, 1, 16, 0, 0, None) == nat.GGQ_ERR_ALIGN
+    assert lib.ggq_overlap_prefetch(h, 0, -1, q4k, 16, 1, 16, 0, 5, None) == nat.GGQ_ERR_ARG        # bad out dtype
+    assert lib.ggq_overlap_copy(h, 7, 4096, 4096, 16) == nat.GGQ_ERR_ARG and lib.ggq_overlap_copy(h, 0, None, 4096, 16) == nat.GGQ_ERR_ARG
     assert lib.ggq_overlap_wait(h, 5, None) == nat.GGQ_ERR_ARG and lib.ggq_overlap_wait(None, 0, None) == nat.GGQ_ERR_ARG
-    # a real round trip through the raw entry points: prefetch on the side stream, wait on the main one, compare with the oracle
+    # a real round trip through the raw entry points: pinned host bytes -> copy stream -> staging slot 2 -> unpack stream -> dense slot 1,
+    # the main stream waits, compare with the oracle
     q = pkg.qtypes.Q.Q4_K
     blocks = pkg.synth.make_blocks(q, 100, seed=3)
-    d = torch.from_numpy(blocks.reshape(-1).copy()).to(DEV)
+    host = torch.from_numpy(blocks.reshape(-1).copy()).pin_memory()
+    d = torch.empty(host.numel(), dtype=torch.uint8, device=DEV)
     out = torch.empty(100 * 256, dtype=torch.float16, device=DEV)
-    s = torch.cuda.current_stream(DEV).cuda_stream
-    assert lib.ggq_overlap_prefetch(h, 1, q4k, None, d.data_ptr(), d.numel(), 100, out.data_ptr(), 0, 0, s) == nat.GGQ_OK
+    torch.cuda.synchronize()
+    assert lib.ggq_overlap_copy(h, 2, host.data_ptr(), d.data_ptr(), host.numel()) == nat.GGQ_OK
+    assert lib.ggq_overlap_prefetch(h, 1, 2, q4k, d.data_ptr(), 100, out.data_ptr(), 0, 0, s) == nat.GGQ_OK
     assert lib.ggq_overlap_wait(h, 1, s) == nat.GGQ_OK
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint16), oracle.dequant_f16(q, blocks).view(np.uint16))
+    # ... and the staging slot may be rewritten right away: the copy waits for the unpack that read it
+    blocks2 = pkg.synth.make_blocks(q, 100, seed=4)
+    host2 = torch.from_numpy(blocks2.reshape(-1).copy()).pin_memory()
+    out2 = torch.empty_like(out)
+    assert lib.ggq_overlap_copy(h, 2, host2.data_ptr(), d.data_ptr(), host2.numel()) == nat.GGQ_OK
+    assert lib.ggq_overlap_prefetch(h, 0, 2, q4k, d.data_ptr(), 100, out2.data_ptr(), 0, 0, s) == nat.GGQ_OK
+    assert lib.ggq_overlap_wait(h, 0, s) == nat.GGQ_OK
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy().view(np.uint16), oracle.dequant_f16(q, blocks2).view(np.uint16))
     lib.ggq_overlap_destroy(h)
