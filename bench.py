@@ -561,6 +561,18 @@ def main():
                 sub = run_flux(pkg, args, 0, 1, device, lambda: torch.cuda.synchronize(device), workload=wl_name, cpu_seconds=min(args.cpu_seconds, 6.0))
                 subs[wl_name] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline")}
                 torch.cuda.empty_cache()
+            # ... and configs[3] STREAMED: the same FLUX set as a synthetic .gguf file -> native parse -> threaded pread -> pinned -> HBM -> dense
+            # (the PCIe-inclusive rate of the boundary; never `value`).  Needs ~7 GB of scratch disk: skipped with the reason if that fails.
+            try:
+                steps = args.steps
+                args.steps = 2
+                sub = run_flux_gguf(pkg, args, device)
+                args.steps = steps
+                subs["flux-gguf"] = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline")}
+            except (OSError, RuntimeError, MemoryError) as e:
+                args.steps = steps
+                subs["flux-gguf"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
             result["workloads"] = subs
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -6,7 +6,8 @@
 //      straight from ggq_device.hpp, over a working set >> the 256 MiB Infinity Cache.
 // Build: see tests/microbench/Makefile.   Run: ./ggq_microbench [parity|ceil|variants|formats|all]
 #include "../../comfyui-gguf_amd/csrc/ggq_device.hpp"
-#include "ggq_lab_engine.hpp"      // the engine with its experiment knobs (XCD / DIRECT / THR / R / LPOL): ggq::lab
+#include "ggq_lab_engine.hpp"
+#include <chrono>      // the engine with its experiment knobs (XCD / DIRECT / THR / R / LPOL): ggq::lab
 #include "ggq_stream.hpp"
 #include "../../include/ggq.h"
 
@@ -942,6 +943,43 @@ static void pmc3_sequence()
     HIP_CHECK(hipFree(a)); HIP_CHECK(hipFree(b));
 }
 
+// Host cost of ONE kernel launch (the floor under dequantize_tensor's per-call cost): hipLaunchKernelGGL as the library issues it, against
+// hipModuleLaunchKernel on a hipFunction_t resolved once (hipGetFuncBySymbol) -- same kernel, same arguments, a 16-block tensor.
+static void launch_cost()
+{
+    using K = ggq::FmtQ4_K;
+    const uint64_t n = 16;
+    uint8_t *dp, *dout;
+    HIP_CHECK(hipMalloc(&dp, n * K::TS)); HIP_CHECK(hipMalloc(&dout, n * K::BS * 2));
+    HIP_CHECK(hipMemset(dp, 0, n * K::TS));
+    ggq::Desc d{dp, dout, n, 0};
+    uint64_t groups = 1; uint32_t xrun = 0;
+    auto kern = ggq::dequant_one<K, 16, ggq::OUT_F16, true, true, 4, ggq::AR_F16, true>;
+    hipFunction_t fn = nullptr;
+    const hipError_t ge = hipGetFuncBySymbol(&fn, reinterpret_cast<const void*>(kern));
+    printf("LAUNCH hipGetFuncBySymbol: %s\n", hipGetErrorString(ge));
+    for (int rep = 0; rep < 3; rep++) {
+        const int N = 20000;
+        HIP_CHECK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < N; i++) hipLaunchKernelGGL(kern, dim3(1), dim3(256), 0, nullptr, d, groups, xrun);
+        auto t1 = std::chrono::steady_clock::now();
+        HIP_CHECK(hipDeviceSynchronize());
+        double a = std::chrono::duration<double, std::micro>(t1 - t0).count() / N;
+        double b = -1;
+        if (ge == hipSuccess) {
+            void* args[] = {&d, &groups, &xrun};
+            t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < N; i++) (void)hipModuleLaunchKernel(fn, 1, 1, 1, 256, 1, 1, 0, nullptr, args, nullptr);
+            t1 = std::chrono::steady_clock::now();
+            HIP_CHECK(hipDeviceSynchronize());
+            b = std::chrono::duration<double, std::micro>(t1 - t0).count() / N;
+        }
+        printf("LAUNCH host us per launch: hipLaunchKernelGGL %.3f   hipModuleLaunchKernel %.3f\n", a, b);
+    }
+    HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(dout));
+}
+
 static void pmc_sequence()
 {
     const uint64_t bytes = 1ull << 30;
@@ -1165,6 +1203,7 @@ int main(int argc, char** argv)
     if (what == "skel") skeletons();
     if (what == "pmc2") pmc2_sequence();
     if (what == "pmc3") pmc3_sequence();
+    if (what == "launchcost") launch_cost();
     if (what == "ablayer") {
         // FLUX 3072x3072 / 9216x3072 / 12288x3072 / 21504x3072, T5 4096x4096, SD3.5 2432x2432 (as 23 x 256 x 1024) and 7296x2432, a small one
         ab_layer<ggq::FmtQ4_K, 8>("Q4_K", 7, {1ull << 21, 23ull * 256 * 1024, 3072ull * 3072, 4096ull * 4096, 9216ull * 3072, 12288ull * 3072, 21504ull * 3072});
