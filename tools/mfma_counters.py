@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Driver for the SQ / TCP / TCC counter passes over the MFMA kernel (ggq::linear_mfma): runs it on a Q4_K 12288x3072 weight for a few
+(rows of x, tile) pairs; `tools/mfma_counters.sh` wraps it in rocprofv3 --pmc passes and prints the per-launch table."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ggq_pkg import load_package  # noqa: E402
+
+pkg = load_package()
+dev = torch.device("cuda:0")
+q = pkg.qtypes.Q.Q4_K
+bs, ts = pkg.qtypes.block_geometry(q)
+g = torch.Generator(device=dev).manual_seed(0)
+rows, cols = 12288, 3072
+pool = []
+for i in range(6):
+    data = torch.randint(0, 256, (rows * cols // bs, ts), dtype=torch.uint8, device=dev, generator=g)
+    for off in pkg.qtypes.SCALE_FIELDS[q]:
+        vals = (torch.rand(data.shape[0], device=dev, generator=g) * 1e-3 + 1e-4).to(torch.float16)
+        data[:, off:off + 2] = vals.view(torch.uint8).reshape(-1, 2)
+    pool.append(pkg.ops.GGMLTensor(data.reshape(-1), tensor_type=q, tensor_shape=(rows, cols)))
+for m, t in ((32, 32), (128, 64), (256, 64), (512, 128)):
+    x = torch.randn(m, cols, device=dev, dtype=torch.bfloat16) * 0.05
+    for w in pool:
+        pkg.fused.linear_mfma(x, w, tile_rows=t)
+    torch.cuda.synchronize()
