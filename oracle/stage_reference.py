@@ -47,6 +47,10 @@ def stage(source_dir=SOURCE_DIR, stage_dir=STAGE_DIR):
         manifest[rel] = _sha256(dst)
     with open(os.path.join(stage_dir, "MANIFEST.json"), "w") as f:
         json.dump({"source": source_dir, "sha256": manifest}, f, indent=1, sort_keys=True)
+    with open(os.path.join(stage_dir, "README.txt"), "w") as f:
+        f.write("VERBATIM copies of four files of city96/ComfyUI-GGUF, staged at build time by oracle/stage_reference.py so that the GPU box\n"
+                "(which has no /root/reference) can run install() over the reference's real classes and time its own torch-CPU path.\n"
+                "Test infrastructure only: git-ignored (never committed), never imported by the product, checked against MANIFEST.json before use.\n")
     return manifest
 
 
