@@ -62,7 +62,7 @@ def test_bench_pool_two_ranks_on_one_gpu():
     assert two["config"]["bytes_per_step_per_gpu"] == one["config"]["bytes_per_step_per_gpu"]        # weak scaling: same pool per rank
     assert len(two["config"]["timed_regions_ms_per_step"]) == 3
     # two ranks time-share one device: each needs about twice as long per step, the aggregate stays at the device's rate
-    # (measured 0.97-1.01 and 1.98-2.06; the bounds leave room for a noisy box, not for a broken reduction)
+    # (measured: aggregate x1.07 at 2 ranks, x1.04 at 4; step time x1.87 / x3.83 -- the bounds leave room for a noisy box, not for a broken reduction)
     ratio = two["value"] / one["value"]
     assert 0.75 <= ratio <= 1.15, (one["value"], two["value"])
     assert 1.5 <= two["ms_per_step"] / one["ms_per_step"] <= 2.7
