@@ -200,7 +200,9 @@ def fast():
     spec = importlib.util.spec_from_file_location("_ggq_fast", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    mod.bind(ctypes.cast(lib().ggq_dequant, ctypes.c_void_p).value)
+    L = lib()
+    mod.bind(ctypes.cast(L.ggq_dequant, ctypes.c_void_p).value)
+    mod.bind_linear(ctypes.cast(L.ggq_linear_small, ctypes.c_void_p).value, ctypes.cast(L.ggq_linear_mfma, ctypes.c_void_p).value)
     return mod
 
 

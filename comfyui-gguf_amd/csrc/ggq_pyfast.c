@@ -1,4 +1,5 @@
-/* ggq_pyfast.c -- a CPython binding of ONE entry point of the C ABI, ggq_dequant (include/ggq.h), for the per-layer hot loop.
+/* ggq_pyfast.c -- a CPython binding of the per-layer entry points of the C ABI (include/ggq.h): ggq_dequant, and the two opt-in fused
+ * linears ggq_linear_small / ggq_linear_mfma, for the per-layer hot loop.
  *
  * ComfyUI calls dequantize_tensor once per quantized layer per forward (reference ops.py:177) and the kernel behind it runs for a
  * few microseconds, so the host side of the call is part of the hot path.  ctypes spends ~0.5 us converting the seven arguments;
@@ -11,7 +12,11 @@
 #include <stdint.h>
 
 typedef int (*ggq_dequant_fn)(int, const void*, uint64_t, void*, int, int, void*);
+typedef int (*ggq_linear_small_fn)(int, const void*, uint32_t, uint32_t, const void*, uint32_t, const void*, void*, int, void*);
+typedef int (*ggq_linear_mfma_fn)(int, const void*, uint32_t, uint32_t, const void*, uint32_t, const void*, void*, int, int, void*);
 static ggq_dequant_fn g_dequant = NULL;
+static ggq_linear_small_fn g_small = NULL;
+static ggq_linear_mfma_fn g_mfma = NULL;
 
 static PyObject* fast_bind(PyObject* self, PyObject* arg)
 {
@@ -20,6 +25,59 @@ static PyObject* fast_bind(PyObject* self, PyObject* arg)
     if (p == NULL && PyErr_Occurred()) return NULL;
     g_dequant = (ggq_dequant_fn)p;
     Py_RETURN_NONE;
+}
+
+/* bind_linear(address of ggq_linear_small, address of ggq_linear_mfma) */
+static PyObject* fast_bind_linear(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
+{
+    (void)self;
+    if (nargs != 2) {
+        PyErr_SetString(PyExc_TypeError, "bind_linear(addr_small, addr_mfma)");
+        return NULL;
+    }
+    void* a = PyLong_AsVoidPtr(args[0]);
+    void* b = PyLong_AsVoidPtr(args[1]);
+    if (PyErr_Occurred()) return NULL;
+    g_small = (ggq_linear_small_fn)a;
+    g_mfma = (ggq_linear_mfma_fn)b;
+    Py_RETURN_NONE;
+}
+
+static int as_u64s(PyObject* const* args, Py_ssize_t n, unsigned long long* out)
+{
+    for (Py_ssize_t i = 0; i < n; i++) {
+        out[i] = (args[i] == Py_None) ? 0ull : PyLong_AsUnsignedLongLong(args[i]);
+        if (out[i] == (unsigned long long)-1 && PyErr_Occurred()) return -1;
+    }
+    return 0;
+}
+
+/* linear_small(qtype, packed, rows, cols, x, m, bias | None, y, dtype, stream) -> ggq_status */
+static PyObject* fast_linear_small(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
+{
+    (void)self;
+    unsigned long long v[10];
+    if (nargs != 10 || g_small == NULL) {
+        PyErr_SetString(PyExc_TypeError, "linear_small(qtype, packed, rows, cols, x, m, bias, y, dtype, stream) after bind_linear()");
+        return NULL;
+    }
+    if (as_u64s(args, 10, v)) return NULL;
+    return PyLong_FromLong(g_small((int)v[0], (const void*)(uintptr_t)v[1], (uint32_t)v[2], (uint32_t)v[3], (const void*)(uintptr_t)v[4], (uint32_t)v[5],
+                                   (const void*)(uintptr_t)v[6], (void*)(uintptr_t)v[7], (int)v[8], (void*)(uintptr_t)v[9]));
+}
+
+/* linear_mfma(qtype, packed, rows, cols, x, m, bias | None, y, dtype, tile_rows, stream) -> ggq_status */
+static PyObject* fast_linear_mfma(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
+{
+    (void)self;
+    unsigned long long v[11];
+    if (nargs != 11 || g_mfma == NULL) {
+        PyErr_SetString(PyExc_TypeError, "linear_mfma(qtype, packed, rows, cols, x, m, bias, y, dtype, tile_rows, stream) after bind_linear()");
+        return NULL;
+    }
+    if (as_u64s(args, 11, v)) return NULL;
+    return PyLong_FromLong(g_mfma((int)v[0], (const void*)(uintptr_t)v[1], (uint32_t)v[2], (uint32_t)v[3], (const void*)(uintptr_t)v[4], (uint32_t)v[5],
+                                  (const void*)(uintptr_t)v[6], (void*)(uintptr_t)v[7], (int)v[8], (int)v[9], (void*)(uintptr_t)v[10]));
 }
 
 /* dequant(qtype, packed_ptr, n_blocks, out_ptr, compute_dtype, out_dtype, stream) -> ggq_status */
@@ -49,6 +107,9 @@ static PyObject* fast_dequant(PyObject* self, PyObject* const* args, Py_ssize_t 
 static PyMethodDef fast_methods[] = {
     {"bind", (PyCFunction)fast_bind, METH_O, "bind(address of ggq_dequant)"},
     {"dequant", (PyCFunction)(void (*)(void))fast_dequant, METH_FASTCALL, "ggq_dequant through a plain function pointer"},
+    {"bind_linear", (PyCFunction)(void (*)(void))fast_bind_linear, METH_FASTCALL, "bind_linear(address of ggq_linear_small, address of ggq_linear_mfma)"},
+    {"linear_small", (PyCFunction)(void (*)(void))fast_linear_small, METH_FASTCALL, "ggq_linear_small through a plain function pointer"},
+    {"linear_mfma", (PyCFunction)(void (*)(void))fast_linear_mfma, METH_FASTCALL, "ggq_linear_mfma through a plain function pointer"},
     {NULL, NULL, 0, NULL},
 };
 

@@ -15,53 +15,90 @@ fp32 summation order -- parity is a tolerance against an fp32 reference (tests/t
 import torch
 
 from . import _native
-from .dequant import GGQUnsupported, _DEVICE_OK, _HIP_TABLE, _OUT_CODE, _device_served, _qtype_key, _raw_stream, dequantize_tensor, is_quantized
+from .dequant import GGQUnsupported, _DEVICE_OK, _HIP_TABLE, _OUT_CODE, _cur_device, _device_served, _qtype_key, _raw_stream, dequantize_tensor, is_quantized
 
 MAX_ROWS = 4
+_F16, _BF16 = torch.float16, torch.bfloat16
+_small_call = None        # ggq_linear_small / ggq_linear_mfma: the CPython binding (csrc/ggq_pyfast.c) when built, else ctypes -- same C entry points
+_mfma_call = None
 
 
-def linear_small(x, weight, bias=None, dequant_dtype=None):
-    """x: (..., cols) on the GPU with at most MAX_ROWS rows in total; weight: GGMLTensor of logical shape (rows, cols).
-    Raises GGQUnsupported for anything the kernel does not take (the caller keeps dequantize + F.linear)."""
-    if dequant_dtype not in (None, torch.float16):
-        raise GGQUnsupported("the fused linear computes the stock fp16 weight values only")
-    if getattr(weight, "patches", None) or getattr(bias, "patches", None):
+def _bind():
+    global _small_call, _mfma_call
+    fast = _native.fast()
+    L = _native.lib()
+    _small_call = fast.linear_small if fast is not None else L.ggq_linear_small
+    _mfma_call = fast.linear_mfma if fast is not None else L.ggq_linear_mfma
+
+
+def _prepare(x, weight, bias, dequant_dtype, what, dtypes, need_cols_256):
+    """The checks both fused kernels share; returns (qid, rows, cols, m, x as (m, cols), bias tensor or None).  Raises GGQUnsupported for
+    anything the kernels do not take.  Kept flat: these calls sit on the per-layer hot path of small-batch / text-encoder runs, where the
+    host's issue rate is the limit."""
+    if dequant_dtype is not None and dequant_dtype is not _F16:
+        raise GGQUnsupported(f"{what} computes the stock fp16 weight values only")
+    if getattr(weight, "patches", None) or (bias is not None and getattr(bias, "patches", None)):
         # get_weight applies LoRA patches to the weight AND to the bias (ops.py:183-190 via ops.py:205-206)
         raise GGQUnsupported("LoRA-patched weight or bias: needs the reference's get_weight")
     qtype = getattr(weight, "tensor_type", None)
-    key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
-    if key not in _HIP_TABLE:
-        raise GGQUnsupported(f"no fused linear for qtype {getattr(qtype, 'name', qtype)!r}")
-    shape = tuple(getattr(weight, "tensor_shape", ()))
-    if len(shape) != 2 or not x.is_cuda or not weight.is_cuda or x.dtype not in _OUT_CODE or x.shape[-1] != shape[1]:
-        raise GGQUnsupported("fused linear: 2-D weight, GPU tensors, fp16 / bf16 / fp32 input of matching width")
-    rows, cols = shape
-    m = x.numel() // cols if cols else 0
-    if not 1 <= m <= MAX_ROWS:
-        raise GGQUnsupported(f"fused linear takes 1..{MAX_ROWS} input rows, got {m}")
-    xf = x.reshape(m, cols)
+    ent = _HIP_TABLE.get(qtype)
+    if ent is None:
+        ent = _HIP_TABLE.get(_qtype_key(qtype))
+        if ent is None:
+            raise GGQUnsupported(f"no {what} for qtype {getattr(qtype, 'name', qtype)!r}")
+    shape = getattr(weight, "tensor_shape", ())
+    if len(shape) != 2:
+        raise GGQUnsupported(f"{what}: 2-D weight")
+    rows, cols = int(shape[0]), int(shape[1])
+    if (not x.is_cuda or x.dtype not in dtypes or x.shape[-1] != cols or cols == 0 or (need_cols_256 and cols % 256) or x.numel() == 0):
+        raise GGQUnsupported(f"{what}: GPU tensors, {'fp16 / bf16' if need_cols_256 else 'fp16 / bf16 / fp32'} input of matching width"
+                             + (", cols % 256 == 0" if need_cols_256 else ""))
+    m = x.numel() // cols
+    xf = x if x.dim() == 2 else x.reshape(m, cols)
     if not xf.is_contiguous() or xf.data_ptr() & 15:
         xf = xf.contiguous().clone()
     if bias is not None:
         if is_quantized(bias):
             bias = dequantize_tensor(bias, x.dtype)
-        bias = bias.to(device=x.device, dtype=x.dtype).contiguous()
+        if type(bias) is not torch.Tensor:
+            bias = bias.as_subclass(torch.Tensor)
+        if bias.device != x.device or bias.dtype is not x.dtype or not bias.is_contiguous():
+            bias = bias.to(device=x.device, dtype=x.dtype).contiguous()
         if bias.numel() != rows:
             raise GGQUnsupported("bias does not match the weight's rows")
+    return ent[0], rows, cols, m, xf, bias
+
+
+def _run(call, name, qid, weight, rows, cols, xf, m, bias, x, extra):
     with torch._C.DisableTorchFunctionSubclass():
-        if weight.dtype is not torch.uint8 or not weight.is_contiguous() or weight.data_ptr() & 15:
-            raise GGQUnsupported("packed weight must be a contiguous, 16-byte aligned byte tensor")
+        if not weight.is_cuda or weight.dtype is not torch.uint8 or not weight.is_contiguous() or weight.data_ptr() & 15:
+            raise GGQUnsupported("packed weight must be a contiguous, 16-byte aligned byte tensor on the GPU")
         index = x.device.index
         if not (_DEVICE_OK.get(index) or _device_served(index)):
             raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
         y = torch.empty((m, rows), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(index):
-            rc = _native.lib().ggq_linear_small(_HIP_TABLE[key][0], weight.data_ptr(), rows, cols, xf.data_ptr(), m,
-                                                None if bias is None else bias.data_ptr(), y.data_ptr(), _OUT_CODE[x.dtype], _raw_stream(index))
+        args = (qid, weight.data_ptr(), rows, cols, xf.data_ptr(), m, None if bias is None else bias.data_ptr(), y.data_ptr(), _OUT_CODE[x.dtype]) + extra
+        if _cur_device() != index:
+            with torch.cuda.device(index):
+                rc = call(*args, _raw_stream(index))
+        else:
+            rc = call(*args, _raw_stream(index))
     if rc == _native.GGQ_ERR_ARG:
-        raise GGQUnsupported("shape outside what the fused kernel stages in LDS")
-    _native.check(rc, "ggq_linear_small")
-    return y.reshape(*x.shape[:-1], rows)
+        raise GGQUnsupported(f"shape outside what {name} takes")
+    if rc:
+        _native.check(rc, name)
+    return y if x.dim() == 2 else y.reshape(*x.shape[:-1], rows)
+
+
+def linear_small(x, weight, bias=None, dequant_dtype=None):
+    """x: (..., cols) on the GPU with at most MAX_ROWS rows in total; weight: GGMLTensor of logical shape (rows, cols).
+    Raises GGQUnsupported for anything the kernel does not take (the caller keeps dequantize + F.linear)."""
+    qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused linear", _OUT_CODE, False)
+    if not 1 <= m <= MAX_ROWS:
+        raise GGQUnsupported(f"fused linear takes 1..{MAX_ROWS} input rows, got {m}")
+    if _small_call is None:
+        _bind()
+    return _run(_small_call, "ggq_linear_small", qid, weight, rows, cols, xf, m, bias, x, ())
 
 
 def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0):
@@ -69,40 +106,7 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0):
     blocks (include/ggq.h ``ggq_linear_mfma``).  x: (..., cols) fp16 / bf16 on the GPU; weight: GGMLTensor of logical shape
     (rows, cols) with cols % 256 == 0.  Weights bit-identical to the reference's; fp32 accumulation in the kernel's own order
     (tolerance parity, tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take."""
-    if dequant_dtype not in (None, torch.float16):
-        raise GGQUnsupported("the fused GEMM computes the stock fp16 weight values only")
-    if getattr(weight, "patches", None) or getattr(bias, "patches", None):
-        raise GGQUnsupported("LoRA-patched weight or bias: needs the reference's get_weight")
-    qtype = getattr(weight, "tensor_type", None)
-    key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
-    if key not in _HIP_TABLE:
-        raise GGQUnsupported(f"no fused GEMM for qtype {getattr(qtype, 'name', qtype)!r}")
-    shape = tuple(getattr(weight, "tensor_shape", ()))
-    if (len(shape) != 2 or not x.is_cuda or not weight.is_cuda or x.dtype not in (torch.float16, torch.bfloat16)
-            or x.shape[-1] != shape[1] or shape[1] % 256 or x.numel() == 0):
-        raise GGQUnsupported("fused GEMM: 2-D weight with cols % 256 == 0, GPU tensors, fp16 / bf16 input of matching width")
-    rows, cols = shape
-    m = x.numel() // cols
-    xf = x.reshape(m, cols)
-    if not xf.is_contiguous() or xf.data_ptr() & 15:
-        xf = xf.contiguous().clone()
-    if bias is not None:
-        if is_quantized(bias):
-            bias = dequantize_tensor(bias, x.dtype)
-        bias = bias.to(device=x.device, dtype=x.dtype).contiguous()
-        if bias.numel() != rows:
-            raise GGQUnsupported("bias does not match the weight's rows")
-    with torch._C.DisableTorchFunctionSubclass():
-        if weight.dtype is not torch.uint8 or not weight.is_contiguous() or weight.data_ptr() & 15:
-            raise GGQUnsupported("packed weight must be a contiguous, 16-byte aligned byte tensor")
-        index = x.device.index
-        if not (_DEVICE_OK.get(index) or _device_served(index)):
-            raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
-        y = torch.empty((m, rows), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(index):
-            rc = _native.lib().ggq_linear_mfma(_HIP_TABLE[key][0], weight.data_ptr(), rows, cols, xf.data_ptr(), m,
-                                               None if bias is None else bias.data_ptr(), y.data_ptr(), _OUT_CODE[x.dtype], int(tile_rows), _raw_stream(index))
-    if rc == _native.GGQ_ERR_ARG:
-        raise GGQUnsupported("shape outside what the fused GEMM takes")
-    _native.check(rc, "ggq_linear_mfma")
-    return y.reshape(*x.shape[:-1], rows)
+    qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
+    if _mfma_call is None:
+        _bind()
+    return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),))
