@@ -43,11 +43,14 @@ static PyObject* fast_bind_linear(PyObject* self, PyObject* const* args, Py_ssiz
     Py_RETURN_NONE;
 }
 
+/* integers and addresses alike (user-space addresses fit a signed 64-bit); None = NULL; a negative int (an invalid tile size, say) passes
+ * through to the C entry point, which answers with GGQ_ERR_ARG as it does for ctypes */
 static int as_u64s(PyObject* const* args, Py_ssize_t n, unsigned long long* out)
 {
     for (Py_ssize_t i = 0; i < n; i++) {
-        out[i] = (args[i] == Py_None) ? 0ull : PyLong_AsUnsignedLongLong(args[i]);
-        if (out[i] == (unsigned long long)-1 && PyErr_Occurred()) return -1;
+        const long long v = (args[i] == Py_None) ? 0ll : PyLong_AsLongLong(args[i]);
+        if (v == -1 && PyErr_Occurred()) return -1;
+        out[i] = (unsigned long long)v;
     }
     return 0;
 }
