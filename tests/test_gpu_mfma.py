@@ -92,3 +92,26 @@ def test_mfma_linear_limits(pkg):
     assert lib.ggq_linear_mfma(12, 16, 32, 256, 16, 1, None, 16, 2, 0, None) == nat.GGQ_ERR_ARG      # fp32
     assert lib.ggq_linear_mfma(12, 24, 32, 256, 16, 1, None, 16, 1, 0, None) == nat.GGQ_ERR_ALIGN
     assert lib.ggq_linear_mfma(12, None, 0, 256, None, 1, None, None, 1, 0, None) == nat.GGQ_OK       # nothing to do
+
+
+def test_mfma_randomized_sweep(pkg):
+    """80 seeded random cases: format, dtype, rows (ragged against 32), cols (1..14 spans of 256), rows of x (1..700), tile, bias."""
+    rng = np.random.default_rng(2026)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for case in range(80):
+        name = ALL[int(rng.integers(len(ALL)))]
+        kind = ("f16", "bf16")[int(rng.integers(2))]
+        q = pkg.qtypes.Q[name]
+        dtype, eps = DT[kind]
+        rows, cols = int(rng.integers(1, 400)), 256 * int(rng.integers(1, 15))
+        m = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 128, 129, 257, 700]))
+        tile = int(rng.choice([0, 0, 32, 64, 128, 256]))
+        blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=1000 + case, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
+        bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if rng.integers(2) else None
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile)
+        try:
+            _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {name} {kind} rows={rows} cols={cols} m={m} tile={tile} bias={bias is not None}: {e}") from None

@@ -190,3 +190,31 @@ def test_c_abi_argument_checks(pkg):
     torch.cuda.synchronize()
     assert np.array_equal(out2.cpu().numpy().view(np.uint16), oracle.dequant_f16(q, blocks2).view(np.uint16))
     lib.ggq_overlap_destroy(h)
+
+
+@pytest.mark.parametrize("wdev", ["cuda:0", "cpu"], ids=["resident", "lowvram"])
+def test_random_call_orders_stay_bit_identical(pkg, attached, wdev):
+    """400 calls in a seeded random order over 9 layers (repeats, reversals, a LoRA-patched layer toggling on and off, two dtypes): whatever
+    the prefetcher predicted, staged or threw away, every output equals the plain path's."""
+    import random
+    rnd = random.Random(7)
+    layers = _layers(pkg, SPECS + [("Q5_1", 384, 512, False), ("Q3_K", 256, 768, True)], wdev, seed=300)
+    xs = {dt: _inputs(layers, 5, dt) for dt in (torch.bfloat16, torch.float16)}
+    plain = pkg.ops.GGMLLayer.cast_bias_weight.__wrapped__
+    want = {}
+    for dt in xs:
+        for i, (lin, _, _) in enumerate(layers):
+            w, b = plain(lin, xs[dt][i])
+            want[(dt, i, False)] = torch.nn.functional.linear(xs[dt][i], w, b)
+    order = list(range(len(layers)))
+    for step in range(400):
+        if step % 40 == 0:
+            rnd.shuffle(order)                                   # a new "model": another fixed order for a while
+        i = order[step % len(order)] if rnd.random() < 0.85 else rnd.randrange(len(layers))
+        dt = torch.bfloat16 if (step // 100) % 2 == 0 else torch.float16
+        lin = layers[i][0]
+        patched = i == 4 and (step // 25) % 2 == 1
+        lin.weight.patches = [("patch", "key")] if patched else []
+        assert torch.equal(lin(xs[dt][i]), want[(dt, i, False)]), (step, i, dt, patched)   # (the stand-in applies no LoRA: same values)
+    st = attached.stats()
+    assert st["hits"] > 100 and st["mispredicted"] + st["misses"] > 20
