@@ -70,8 +70,9 @@ template <class F> struct TuneMid {
     static constexpr uint32_t XRUN_LOG2 = 0;
 };
 constexpr uint64_t MID_MIN_ELEMENTS = 1ull << 23, MID_MAX_ELEMENTS = 1ull << 25;
+// ... for every format, the one-wave-team formats included (`ablayer2`: Q3_K 9.4 M 3635 -> 4802 GB/s, 16.8 M 4469 -> 5688, 28.3 M 4592 -> 5821;
+// Q6_K 4756 -> 5082 / 4690 -> 5462 / 5172 -> 5629; Q2_K and IQ4_XS like Q4_K).
 template <class F> struct MidShape { static constexpr bool V = true; };
-template <> struct MidShape<FmtQ3_K> { static constexpr bool V = false; };      // not measured at layer size: keeps its shape
 
 // Tune<F> = the shape for the stock fp16 arithmetic and fp16 output; TuneFor<F, ARITH, OUT> below picks per mode.
 #ifdef GGQ_SOLO_ONLY      /* A/B builds only: one-wave teams for every format */

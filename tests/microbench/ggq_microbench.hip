@@ -1210,6 +1210,12 @@ int main(int argc, char** argv)
         ab_layer<ggq::FmtQ5_0, 64>("Q5_0", 2, {2432ull * 2432, 7296ull * 2432, 3072ull * 3072});
         ab_layer<ggq::FmtQ8_0, 64>("Q8_0", 4, {3072ull * 3072, 4096ull * 4096, 12288ull * 3072});
     }
+    if (what == "ablayer2") {     // the formats whose whole-model shape is not the 4-wave team: do they want the layer-sized shape too?
+        ab_layer<ggq::FmtQ3_K, 8>("Q3_K", 6, {3072ull * 3072, 4096ull * 4096, 9216ull * 3072});
+        ab_layer<ggq::FmtQ6_K, 8>("Q6_K", 9, {3072ull * 3072, 4096ull * 4096, 9216ull * 3072});
+        ab_layer<ggq::FmtQ2_K, 8>("Q2_K", 5, {3072ull * 3072, 4096ull * 4096});
+        ab_layer<ggq::FmtIQ4_XS, 8>("IQ4_XS", 11, {3072ull * 3072, 4096ull * 4096});
+    }
     if (what == "ab") ab_all();
     if (what == "abxcd") ab_xcd_all();
     if (what == "ceilx") ceilings_x();
