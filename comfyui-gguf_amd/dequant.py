@@ -348,16 +348,21 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
             data = _as_bytes(data)
         if data.numel() != n_rows * (cols // block_size) * type_size:
             raise GGQUnsupported("row lookup: packed bytes do not match the logical shape")
-        idx = indices.reshape(-1).to(torch.int64).contiguous()
+        idx = indices if (indices.dtype is torch.int64 and indices.is_contiguous()) else indices.to(torch.int64).contiguous()
         out = torch.empty(tuple(indices.shape) + (cols,), dtype=out_dtype, device=data.device)
-        if idx.numel():
+        n_idx = idx.numel()
+        if n_idx:
             index = data.device.index
             if not (_DEVICE_OK.get(index) or _device_served(index)):
                 raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
-            with torch.cuda.device(index):
-                rc = _native.lib().ggq_dequant_rows(qid, data.data_ptr(), n_rows, cols // block_size, idx.data_ptr(), idx.numel(), out.data_ptr(),
-                                                    compute_code, _OUT_CODE[out_dtype], _raw_stream(index))
-            _native.check(rc, "ggq_dequant_rows")
+            args = (qid, data.data_ptr(), n_rows, cols // block_size, idx.data_ptr(), n_idx, out.data_ptr(), compute_code, _OUT_CODE[out_dtype])
+            if _cur_device() != index:
+                with torch.cuda.device(index):
+                    rc = _native.lib().ggq_dequant_rows(*args, _raw_stream(index))
+            else:
+                rc = _native.lib().ggq_dequant_rows(*args, _raw_stream(index))
+            if rc:
+                _native.check(rc, "ggq_dequant_rows")
     return out
 
 
