@@ -19,7 +19,8 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 struct ggq_overlap {
     int device = 0, n_slots = 0;
-    hipStream_t unpack = nullptr, copy = nullptr;
+    hipStream_t unpack = nullptr, copy = nullptr, copy2 = nullptr;   // copy2: the second half of every staged weight (two DMA queues keep the link fuller than one)
+    hipEvent_t half = nullptr;
     hipEvent_t main_mark[MAX_SLOTS] = {}, done[MAX_SLOTS] = {};        // per dense slot
     hipEvent_t copied[MAX_SLOTS] = {}, consumed[MAX_SLOTS] = {};       // per packed staging slot
     bool consumed_valid[MAX_SLOTS] = {};
@@ -37,6 +38,8 @@ int ggq_overlap_create(int n_slots, ggq_overlap** out)
     hipError_t e = hipGetDevice(&ov->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ov->unpack, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ov->copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ov->copy2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ov->half, hipEventDisableTiming);
     for (int i = 0; i < n_slots && e == hipSuccess; i++) {
         hipEvent_t* evs[4] = {&ov->main_mark[i], &ov->done[i], &ov->copied[i], &ov->consumed[i]};
         for (hipEvent_t* ev : evs)
@@ -54,8 +57,19 @@ int ggq_overlap_copy(ggq_overlap* ov, int staging_slot, const void* host_packed,
 {
     if (!ov || staging_slot < 0 || staging_slot >= ov->n_slots || (packed_bytes && (!host_packed || !dev_packed))) return GGQ_ERR_ARG;
     hipError_t e = hipSuccess;
-    if (ov->consumed_valid[staging_slot]) e = hipStreamWaitEvent(ov->copy, ov->consumed[staging_slot], 0);   // the unpack that last read this slot
-    if (e == hipSuccess && packed_bytes) e = hipMemcpyAsync(dev_packed, host_packed, (size_t)packed_bytes, hipMemcpyHostToDevice, ov->copy);
+    // weights of a few MB and more go as two halves on two copy streams; `copied` is recorded on the first after it has waited for the second
+    const uint64_t split = packed_bytes >= (4ull << 20) ? ((packed_bytes / 2 + 4095) & ~4095ull) : packed_bytes;
+    if (ov->consumed_valid[staging_slot]) {                                                   // the unpack that last read this slot
+        e = hipStreamWaitEvent(ov->copy, ov->consumed[staging_slot], 0);
+        if (e == hipSuccess && split < packed_bytes) e = hipStreamWaitEvent(ov->copy2, ov->consumed[staging_slot], 0);
+    }
+    if (e == hipSuccess && split) e = hipMemcpyAsync(dev_packed, host_packed, (size_t)split, hipMemcpyHostToDevice, ov->copy);
+    if (e == hipSuccess && split < packed_bytes) {
+        e = hipMemcpyAsync(static_cast<uint8_t*>(dev_packed) + split, static_cast<const uint8_t*>(host_packed) + split, (size_t)(packed_bytes - split),
+                           hipMemcpyHostToDevice, ov->copy2);
+        if (e == hipSuccess) e = hipEventRecord(ov->half, ov->copy2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ov->copy, ov->half, 0);
+    }
     if (e == hipSuccess) e = hipEventRecord(ov->copied[staging_slot], ov->copy);
     return e == hipSuccess ? GGQ_OK : ggq::hip_fail(e);
 }
@@ -92,7 +106,7 @@ int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream)
 void ggq_overlap_destroy(ggq_overlap* ov)
 {
     if (!ov) return;
-    for (hipStream_t s : {ov->copy, ov->unpack})
+    for (hipStream_t s : {ov->copy, ov->copy2, ov->unpack})
         if (s) {
             (void)hipStreamSynchronize(s);
             (void)hipStreamDestroy(s);
@@ -100,6 +114,7 @@ void ggq_overlap_destroy(ggq_overlap* ov)
     for (int i = 0; i < MAX_SLOTS; i++)
         for (hipEvent_t ev : {ov->main_mark[i], ov->done[i], ov->copied[i], ov->consumed[i]})
             if (ev) (void)hipEventDestroy(ev);
+    if (ov->half) (void)hipEventDestroy(ov->half);
     delete ov;
 }
 
