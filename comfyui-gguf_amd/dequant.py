@@ -320,6 +320,10 @@ def dequantize_tensor_via_gpu(tensor, dtype=None, dequant_dtype=None, device=Non
     return dequantize_tensor(carrier, dtype, dequant_dtype).cpu()
 
 
+import os as _os
+_CHECK_INDICES = _os.environ.get("GGQ_CHECK_INDICES", "0") not in ("", "0")
+
+
 def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
     """``F.embedding(indices, dequantize_tensor(tensor, dtype, dequant_dtype))`` without unpacking the whole table: only the
     rows ``indices`` names are dequantized (include/ggq.h ``ggq_dequant_rows``), bit-identical values.  What
@@ -349,6 +353,10 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
         if data.numel() != n_rows * (cols // block_size) * type_size:
             raise GGQUnsupported("row lookup: packed bytes do not match the logical shape")
         idx = indices if (indices.dtype is torch.int64 and indices.is_contiguous()) else indices.to(torch.int64).contiguous()
+        if _CHECK_INDICES:
+            # F.embedding raises a device-side assert on an id outside the table; the kernel clamps.  GGQ_CHECK_INDICES=1 restores the failure
+            # (asynchronously, like torch's own assert) for debugging a tokenizer / vocabulary mismatch.
+            torch._assert_async(((idx >= 0) & (idx < n_rows)).all(), "ggq: token id outside the embedding table")
         out = torch.empty(tuple(indices.shape) + (cols,), dtype=out_dtype, device=data.device)
         n_idx = idx.numel()
         if n_idx:
