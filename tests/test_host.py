@@ -483,3 +483,37 @@ def test_dispatch_tables_equal_the_reference_live(pkg):
               _Carrier(torch.zeros(66, dtype=torch.uint8), Q.IQ2_XXS, torch.Size((256,)))]
     for t in probes:
         assert dq.is_quantized(t) == ref.is_quantized(t) and dq.is_torch_compatible(t) == ref.is_torch_compatible(t), getattr(t, "tensor_type", t)
+
+
+def test_bench_traffic_is_only_reported_for_the_build_it_was_measured_on(pkg, monkeypatch, tmp_path):
+    """bench.load_traffic: the PMC figure of profiles/pmc_traffic.json is reported only when the loaded library's ggq_build_id() equals the
+    id recorded with the counters; otherwise traffic is None and traffic_source says why (Weak #8)."""
+    import json
+    import bench
+    build_id = pkg._native.lib().ggq_build_id().decode()
+    assert build_id == pkg._native.source_id() and len(build_id) == 16            # the in-tree library is stamped with the source identity
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.load_traffic(pkg, "Q4_K:pairs64")[0] is None                       # no file
+    (prof / "pmc_traffic.json").write_text(json.dumps({"_build_id": "0123456789abcdef", "Q4_K:pairs64": 123}))
+    t, src = bench.load_traffic(pkg, "Q4_K:pairs64")
+    assert t is None and "stale" in src and "0123456789abcdef" in src and build_id in src
+    (prof / "pmc_traffic.json").write_text(json.dumps({"_build_id": build_id, "_provenance": "how", "Q4_K:pairs64": 123}))
+    assert bench.load_traffic(pkg, "Q4_K:pairs64") == (123, f"how; library build {build_id}")
+    t, src = bench.load_traffic(pkg, "Q9_Z:pairs64")
+    assert t is None and "no PMC entry" in src
+    # the committed table belongs to the committed kernels
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert committed["_build_id"] == build_id, "profiles/pmc_traffic.json was collected on other dequant kernels: re-run tests/microbench/pmc.sh + tools/pmc_summarize.py --json"
+    assert abs(committed["Q4_K:pairs64"] / 7738490880 - 1.0) < 0.01
+
+
+def test_bench_median_and_min_helper():
+    import time
+    import bench
+    calls = []
+    med, tmin, reps = bench._median_min(lambda: (calls.append(1), time.sleep(0.001)), budget_s=0.0, min_reps=10, warmup=3)
+    assert reps == 10 and len(calls) == 13 and 0.001 <= tmin <= med < 0.05          # >= 3 warm-up, >= 10 timed passes, median and min
+    med, tmin, reps = bench._median_min(lambda: time.sleep(0.001), budget_s=0.05, min_reps=3, warmup=0)
+    assert 20 <= reps <= 200                                                         # ... and as many as the time budget allows
