@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--fused-small-m", action="store_true", help="opt-in fused dequantize + linear for the 1-row (modulation) layers")
     ap.add_argument("--fused-mfma", type=int, default=0, metavar="MAX_M", help="opt-in fused dequantize + GEMM on the matrix cores for inputs of up to MAX_M rows")
     ap.add_argument("--overlap", action="store_true", help="opt-in side-stream prefetch of the next layer's weight (overlap.LayerPrefetcher)")
+    ap.add_argument("--graph", action="store_true", help="also time both steps replayed from a captured HIP graph: GPU time without the host's issue rate")
     ap.add_argument("--lowvram", action="store_true", help="packed weights live on the CPU and are copied per layer per forward (ops.py:209)")
     args = ap.parse_args()
     pkg = load_package()
@@ -92,6 +93,27 @@ def main():
 
     q_med, q_min = timed(step_quantized)
     d_med, d_min = timed(step_dense)
+    graph_ms = None
+    if args.graph and not args.lowvram and not args.overlap:
+        graph_ms = {}
+        for name, fn in (("on_the_fly", step_quantized), ("dense", step_dense)):
+            side = torch.cuda.Stream()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                fn()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.reps):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            graph_ms[name] = round(a.elapsed_time(b) / args.reps, 2)
+            del g
     flops = sum(2.0 * x.shape[0] * lin.weight.shape[0] * lin.weight.shape[1] for lin, x in layers)
     n_el = sum(lin.weight.shape[0] * lin.weight.shape[1] for lin, _ in layers)
     print(json.dumps({
@@ -99,6 +121,7 @@ def main():
         "ms_per_step_dequant_on_the_fly": round(q_med, 2), "ms_per_step_dense_resident": round(d_med, 2),
         "dequant_cost_ms_per_step": round(q_med - d_med, 2), "dequant_share_of_step_pct": round(100 * (q_med - d_med) / q_med, 1),
         "best_ms": {"on_the_fly": round(q_min, 2), "dense": round(d_min, 2)},
+        "graph_replay_ms_per_step": graph_ms,
         "gemm_TFLOPs_dense": round(flops / d_med / 1e9, 1),
         "dense_cache": cache.stats() if cache is not None else None,
         "overlap": prefetcher.stats() if prefetcher is not None else None, "lowvram": args.lowvram,
