@@ -56,7 +56,7 @@ class _Staging:
 
     def __init__(self):
         self.packed = None        # uint8 staging for packed bytes copied from the host
-        self.owner = None         # (id(module), weight version) whose packed bytes were last copied here
+        self.owner = None         # (weak reference to the CPU weight, its version) whose packed bytes were last copied here
 
 
 class _Device:
@@ -157,10 +157,9 @@ class LayerPrefetcher:
                 return None
             host = self._host_bytes(module, w)
         dev = self._dev(index)
-        tag = (id(module), w._version)
         for si, st in enumerate(dev.staging):
-            if st.owner == tag:
-                return si                                     # already on its way (scheduled two layers ahead)
+            if st.owner is not None and st.owner[0]() is w and st.owner[1] == w._version:
+                return si                                     # already on its way (scheduled two layers ahead); identity, not id(): ids are recycled
         si = dev.staging_turn
         st = dev.staging[si]
         nbytes = host.numel()
@@ -171,7 +170,7 @@ class LayerPrefetcher:
         with torch.cuda.device(index):
             rc = _native.lib().ggq_overlap_copy(dev.handle, si, host.data_ptr(), st.packed.data_ptr(), nbytes)
         _native.check(rc, "ggq_overlap_copy")
-        st.owner = tag
+        st.owner = (weakref.ref(w), w._version)
         dev.staging_turn = (si + 1) % N_STAGING
         return si
 
