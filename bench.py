@@ -71,18 +71,8 @@ def max_over_ranks(value, device):
 
 
 def device_blocks(pkg, qtype, n_blocks, device, seed):
-    """Random packed blocks generated ON the device, scale fields overwritten with nominal fp16
-    values (same distribution as comfyui-gguf_amd/synth.py mode 'nominal')."""
-    qt = pkg.qtypes
-    _, ts = qt.block_geometry(qtype)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    blocks = torch.randint(0, 256, (n_blocks, ts), dtype=torch.uint8, device=device, generator=g)
-    lo, hi = (1e-3, 2.1e-2) if qtype in qt.LEGACY_QTYPES else (1e-4, 2e-3)
-    for off in qt.SCALE_FIELDS[qtype]:
-        vals = (torch.rand(n_blocks, device=device, generator=g) * (hi - lo) + lo).to(torch.float16)
-        blocks[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
-    return blocks.reshape(-1)
+    """Random packed blocks generated ON the device, nominal fp16 scale fields (comfyui-gguf_amd/synth.py)."""
+    return pkg.synth.device_blocks(qtype, n_blocks, device, seed)
 
 
 def build_pool(pkg, entries, device, seed0):
@@ -234,6 +224,19 @@ def cpu_baselines(pkg, plan, qtypes, budget_s):
     reference (neither /root/reference nor a staged oracle/_ref) the port IS the baseline, labelled as such."""
     ref = cpu_baseline_reference(pkg, plan, qtypes, budget_s * 0.5)
     port = cpu_baseline_port(pkg, plan, qtypes[0], budget_s * 0.5) if len(set(qtypes[:8])) == 1 else None
+    # parity of the WHOLE launch, outside every timed region: every output tensor of the plan against the oracle (oracle/plan_check.py:
+    # whole tensors vs the AVX2 leg, that leg vs the soft-float checker on three windows per tensor); the reference's own dequantize()
+    # is the checker for the first tensors (cpu_baseline_reference above)
+    from oracle import plan_check
+    t0 = time.perf_counter()
+    n, bad = plan_check.check_plan(plan._keep, qtypes, plan.outputs)
+    head = ref if ref is not None else port
+    if head is not None:
+        ok = not bad and head.get("parity_vs_gpu") == "bit-exact"
+        head["parity_vs_gpu"] = (f"bit-exact ({n} tensors: every output of the timed launch vs the oracle"
+                                 + (", the first 2 also vs the reference's dequantize() on torch-CPU" if ref is not None else "") + ")") if ok else \
+            f"MISMATCH ({len(bad)} of {n} tensors differ from the oracle: {bad[:3]}; first-tensor check {head.get('parity_vs_gpu')})"
+        head["parity_check_s"] = round(time.perf_counter() - t0, 2)
     return (ref, port) if ref is not None else (port, None)
 
 
@@ -381,14 +384,106 @@ def load_traffic(pkg, workload_key):
     return table[workload_key], f"{table.get('_provenance', 'profiles/pmc_traffic.json')}; library build {build_id}"
 
 
-def median_region(pkg, plan, args, device, fence, regions):
+def observed_world(device, rank, use_dist):
+    """What the process group really looks like, gathered from every rank -- so that an N-GPU line proves N ranks on N distinct
+    devices took part (Next #4): group size and backend as torch.distributed reports them, and per rank the device
+    index, name, uuid and PCI bus id."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "device": str(device), "name": props.name, "arch": getattr(props, "gcnArchName", None),
+            "uuid": str(getattr(props, "uuid", "")) or None, "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "total_memory_GB": round(props.total_memory / 1e9, 1), "pid": os.getpid()}
+    if not (use_dist and dist.is_initialized()):
+        return {"size": 1, "backend": None, "ranks": [mine], "distinct_devices": 1}
+    rows = [None] * dist.get_world_size()
+    dist.all_gather_object(rows, mine)
+    ids = {(r["uuid"] or r["pci_bus_id"] or r["device"]) for r in rows}
+    return {"size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": rows, "distinct_devices": len(ids)}
+
+
+def run_per_layer(pkg, args, device, fence):
+    """The call the node really makes (reference ops.py:177): ONE dequantize_tensor() per quantized layer per forward, here over
+    the 304 tensors of the FLUX.1-dev set in model order, bf16 result (FLUX computes in bf16) -- 304 launches per pass instead of
+    the 2 of the whole-set plan.  Two figures, because they answer different questions: `eager` = the python loop as ComfyUI runs it
+    (host enqueue cost included; outputs go back to torch's allocator after every call, as a layer's weight does), `gpu_bound` = the
+    same 304 launches replayed from a captured HIP graph, i.e. what the unpacks cost inside a model step whose queue never runs
+    dry.  Three timed regions of `passes` passes each, median reported, HIP events on the launch stream."""
+    manifest = pkg.manifests.flux_dev(args.mix)
+    tensors = []
+    for i, (_, q, shape) in enumerate(manifest):
+        n_blocks = pkg.synth.n_blocks_for(q, shape[0] * shape[1])
+        tensors.append(pkg.ops.GGMLTensor(device_blocks(pkg, q, n_blocks, device, 7000 + i), tensor_type=q, tensor_shape=shape))
+    nbytes = sum(pkg.sharding.tensor_cost(e) for e in manifest)
+    dq = pkg.dequant.dequantize_tensor
+    dtype = torch.bfloat16
+    passes = max(2, args.steps // 10)
+    stream = torch.cuda.current_stream(device)
+
+    def eager_pass():
+        for t in tensors:
+            dq(t, dtype)
+
+    def region(fn):
+        fence()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record(stream)
+        for _ in range(passes):
+            fn()
+        b.record(stream)
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+        fence()
+        return a.elapsed_time(b) / passes, t_host * 1e3 / passes
+
+    for _ in range(2):
+        eager_pass()
+    eager = sorted(region(eager_pass) for _ in range(args.regions))
+    side = torch.cuda.Stream(device)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        keep = [dq(t, dtype) for t in tensors]                     # warm the allocator on the capture stream
+        torch.cuda.synchronize(device)
+        with torch.cuda.graph(graph, stream=side):
+            keep = [dq(t, dtype) for t in tensors]
+    graph.replay()
+    torch.cuda.synchronize(device)
+    # parity of what the per-layer launches wrote (outside the timed regions): every tensor vs the oracle
+    from oracle import plan_check
+    n, bad = plan_check.check_plan([t.as_subclass(torch.Tensor) for t in tensors], [q for _, q, _ in manifest], keep, windows=False)
+    bound = sorted(region(graph.replay) for _ in range(args.regions))
+    e_ms, e_host = eager[len(eager) // 2]
+    g_ms, _ = bound[len(bound) // 2]
+    del graph, keep
+    gbs = nbytes / (g_ms * 1e-3) / 1e9
+    return {
+        "metric": "dequant GB/s, one dequantize_tensor() launch per layer (packed in -> bf16 out), (in+out) bytes / time",
+        "value": round(gbs, 1), "unit": "GB/s", "ms_per_step": round(g_ms, 5),
+        "config": {"workload": f"FLUX.1-dev weight set ({len(manifest)} tensors, {args.mix}) through the per-layer entry point, one launch per tensor in model "
+                               "order, bf16 result; value = GPU-bound (the launches replayed from a captured HIP graph)",
+                   "launches_per_pass": len(manifest), "passes_per_region": passes, "bytes_per_pass": nbytes,
+                   "gpu_bound_regions_ms": [round(r[0], 5) for r in bound], "eager_regions_ms": [round(r[0], 5) for r in eager],
+                   "eager_ms_per_pass": round(e_ms, 5), "eager_GBps": round(nbytes / (e_ms * 1e-3) / 1e9, 1),
+                   "eager_host_enqueue_us_per_call": round(e_host * 1e3 / len(manifest), 2),
+                   "gpu_bound_us_per_launch": round(g_ms * 1e3 / len(manifest), 3),
+                   "parity_vs_oracle": f"bit-exact ({n} tensors)" if not bad else f"MISMATCH {bad[:3]}"},
+        "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "ggq::dequant_one<Fmt*, ...> (one launch per tensor; team shape picked per tensor size)",
+                     "algorithmic_bytes_per_launch": nbytes // len(manifest), "avg_launch_ms": round(g_ms / len(manifest), 6)},
+        "cpu_baseline": None,
+    }
+
+
+def median_region(pkg, plan, args, device, fence, regions, steps=None, warmup=None):
     """`regions` timed regions of exactly K launches each (the first after W warm-up launches), every one bracketed by the
     fence on both sides and reduced with MAX over ranks; the reported step time is the MEDIAN region's.  Returns
     (ms_per_step of the median region [MAX over ranks], this rank's gpu ms per step in that region, wall ms per step, all regions)."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     rows = []
     for r in range(regions):
-        gpu_ms, wall_ms = timed_steps(plan, args.steps, args.warmup if r == 0 else 0, device, fence)
-        rows.append((max_over_ranks(gpu_ms / args.steps, device), gpu_ms / args.steps, wall_ms / args.steps))
+        gpu_ms, wall_ms = timed_steps(plan, steps, warmup if r == 0 else 0, device, fence)
+        rows.append((max_over_ranks(gpu_ms / steps, device), gpu_ms / steps, wall_ms / steps))
     order = sorted(range(regions), key=lambda k: rows[k][0])
     med = rows[order[regions // 2]]
     return med[0], med[1], med[2], [round(r[0], 5) for r in rows]
@@ -406,7 +501,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline legs (0 = skip)")
     ap.add_argument("--regions", type=int, default=3, help="timed regions of K steps each; the median region is reported")
     ap.add_argument("--no-workloads", action="store_true", help="skip the configs[3] / configs[4] sub-lines of the default run")
-    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf"], help="see the module docstring")
+    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
     ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf: only the first N tensors (smoke runs)")
@@ -452,10 +547,19 @@ def main():
     pkg._native.lib()                       # fail loudly if the HIP extension is missing
     qt = pkg.qtypes
     head_q = qt.Q[args.qtype]
+    world_info = observed_world(device, rank, use_dist)   # every rank takes part (all_gather_object); rank 0 reports it
 
     if args.workload != "pool":
         if args.workload in ("flux", "sd35-t5"):
             result = run_flux(pkg, args, rank, world, device, fence)
+            if result is not None:
+                result["world"] = world_info
+        elif args.workload == "per-layer":
+            if world != 1:
+                sys.exit("--workload per-layer is a single-GPU measurement")
+            result = run_per_layer(pkg, args, device, fence)
+            result.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                           "dtype": "f16", "data": "synthetic"})
         else:
             if world != 1:
                 sys.exit("--workload flux-gguf is a single-GPU measurement")
@@ -499,6 +603,7 @@ def main():
                        "rates_GBps": {"in": round(in_bytes / (gpu_ms_step * 1e-3) / 1e9, 1),
                                       "out": round((bytes_rank - in_bytes) / (gpu_ms_step * 1e-3) / 1e9, 1),
                                       "in_plus_out": round(achieved, 1)}},
+            "world": world_info,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"ggq::dequant_many<Fmt{head_q.name}, ...>", "algorithmic_bytes_per_launch": bytes_rank,
@@ -512,16 +617,19 @@ def main():
         steps_q = max(10, args.steps // 3)
         for q in qt.HIP_QTYPES:
             if q == head_q:
-                per_qtype[q.name] = {"GB/s": result["roofline"]["achieved"], "pct_hbm_peak": round(100 * result["roofline"]["frac"], 2)}
+                per_qtype[q.name] = {"GB/s": result["roofline"]["achieved"], "pct_hbm_peak": round(100 * result["roofline"]["frac"], 2),
+                                     "regions_GBps": [round(bytes_rank / (r * 1e-3) / 1e9, 1) for r in regions]}
                 continue
             p = build_pool(pkg, pkg.manifests.flux_linear_pool(q, args.pairs), device, seed0=50_000 + 100 * int(q))
-            ms, _ = timed_steps(p, steps_q, 3, device, lambda: torch.cuda.synchronize(device))
-            gbs = p.bytes / (ms / steps_q * 1e-3) / 1e9
-            per_qtype[q.name] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2)}
+            _, ms, _, regs = median_region(pkg, p, args, device, fence, args.regions, steps=steps_q, warmup=args.warmup)   # same fences, same median-of-regions as the headline
+            gbs = p.bytes / (ms * 1e-3) / 1e9
+            per_qtype[q.name] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2),
+                                 "regions_GBps": [round(p.bytes / (r * 1e-3) / 1e9, 1) for r in regs]}
             p.close()
             del p
             torch.cuda.empty_cache()
         result["per_qtype"] = per_qtype
+        result["per_qtype_how"] = f"every format: median of {args.regions} timed regions of {steps_q} launches (all listed), {args.warmup} warm-up launches, fences as the headline"
 
     if not args.no_per_mode and rank == 0 and world == 1:
         # the other (dequant_dtype -> dtype) combinations dequantize_tensor can be asked for (dequant.py:15-23,
@@ -535,9 +643,10 @@ def main():
                 if cd == torch.float16 and od == torch.float16:
                     continue
                 p = pkg.grouped.DequantPlan([(d, head_q, sh) for d, sh in zip(plan_head._keep, shapes)], out_dtype=od, dequant_dtype=cd)
-                ms, _ = timed_steps(p, steps_m, 3, device, lambda: torch.cuda.synchronize(device))
-                gbs = p.bytes / (ms / steps_m * 1e-3) / 1e9
-                per_mode[f"{names[cd]}->{names[od]}"] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2)}
+                _, ms, _, regs = median_region(pkg, p, args, device, fence, args.regions, steps=steps_m, warmup=args.warmup)
+                gbs = p.bytes / (ms * 1e-3) / 1e9
+                per_mode[f"{names[cd]}->{names[od]}"] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2),
+                                                         "regions_GBps": [round(p.bytes / (r * 1e-3) / 1e9, 1) for r in regs]}
                 p.close()
                 del p
                 torch.cuda.empty_cache()
@@ -561,6 +670,9 @@ def main():
                 sub = run_flux(pkg, args, 0, 1, device, lambda: torch.cuda.synchronize(device), workload=wl_name, cpu_seconds=min(args.cpu_seconds, 6.0))
                 subs[wl_name] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline")}
                 torch.cuda.empty_cache()
+            # ... the same FLUX set the way the node drives it: one dequantize_tensor() launch per layer, bf16 out (Next #2)
+            subs["per_layer"] = run_per_layer(pkg, args, device, lambda: torch.cuda.synchronize(device))
+            torch.cuda.empty_cache()
             # ... and configs[3] STREAMED: the same FLUX set as a synthetic .gguf file -> native parse -> threaded pread -> pinned -> HBM -> dense
             # (the PCIe-inclusive rate of the boundary; never `value`).  Needs ~7 GB of scratch disk: skipped with the reason if that fails.
             try:

@@ -1,0 +1,253 @@
+// ggq_gemm.hpp -- gfx950 device code: y = x @ dequant(W)^T (+ bias) for MANY rows of x (hundreds to thousands: the token-side
+// linears of a diffusion step), straight from the packed GGUF blocks, on the matrix cores -- the dense weight is never written
+// to memory.  The many-rows end of SURVEY.md section 8f item 4 (reference ops.py:242-244: dequantize the whole weight, F.linear).
+//
+// Why a second MFMA kernel.  ggq_mfma.hpp lets every lane decode the eight weights that are its own MFMA operand: no dense tile
+// anywhere, but every 32..128-row block of x re-decodes every weight it meets, so its cost grows with rows/64 and it loses to
+// "unpack once + hipBLASLt" beyond ~256 rows.  Here the decode is amortised the way a GEMM amortises its operand
+// loads: a workgroup owns a 256 x 256 output tile; per K-step of 32 it decodes its 256 x 32 weight tile ONCE -- 16 weights per
+// thread, the same `fields` / `quad_f16` (+ `.to(dtype)`) code as the dequant kernels, so the weights are the reference's values
+// bit for bit -- into LDS as fp16 / bf16, next to the 256 x 32 tile of x; all 8 waves then read MFMA fragments of both with
+// ds_read_b128.  One decoded weight feeds 256 rows of x instead of 32..128.
+//
+// Shape of the work (8 waves, 512 threads, one workgroup per CU):
+//   * LDS: X[2] and W[2] tiles of 256 rows x 64 B (32 K-elements), double-buffered: 64 KiB; STAGING: the packed bytes of the
+//     tile's 256 weight rows for one 256-element span of K (one K-quant super-block / 8 legacy blocks per row: 36 KiB for Q4_K),
+//     filled with coalesced 16 B/lane loads, the next span's bytes in flight in registers meanwhile;
+//   * tile rows are 64 B; the 16-byte column is XOR-swizzled with ((row >> 3) & 3) ^ ((row >> 1) & 1): ds_read_b128 fragment reads
+//     (one row per lane, gfx950's four non-contiguous 16-lane groups, MI355X_MICROARCH.md LDS) and both writers -- x: 4 lanes per
+//     row; weights: 2 lanes per row, 2 chunks each -- are bank-conflict-free;
+//   * K-step t: [x tile t+1: global -> registers] [decode weight tile t+1 -> W[next]] [MFMAs on X[cur], W[cur]: 2 k-slices of 16,
+//     per wave 2 (n) x 4 (m) tiles of 32 x 32 = 16 v_mfma_f32_32x32x16] [x registers -> X[next]] one s_barrier.  The compiler
+//     interleaves the decode VALU work with the MFMAs; the two waves of a SIMD overlap each other's LDS traffic;
+//   * MFMA operands: A = weights (i = output column n), B = x (j = row m): a lane's accumulator registers then hold FOUR CONSECUTIVE
+//     n of one row m, so the epilogue packs 8-byte pieces, transposes through LDS (XOR-swizzled, wave-private) and stores full
+//     128-byte lines of y with 16 B per lane;
+//   * workgroup -> tile mapping: XCD x (workgroup b runs on XCD b % 8) takes a contiguous eighth of the tiles in column-major
+//     order, so the tiles that run together in one XCD share weight panels (read from HBM once) and x panels in that XCD's L2.
+//
+// Numerics: weights = the reference's values bit for bit; products exact in fp32; fp32 accumulation in k order inside the MFMA,
+// K-steps in order, no K split (deterministic).  Like any GEMM against another GEMM the result differs from hipBLASLt's by
+// summation order: parity is a tolerance against an fp64 evaluation on the oracle's weights plus exact-arithmetic cases
+// (tests/test_gpu_mfma.py), hence OPT-IN.
+#pragma once
+
+#include "ggq_mfma.hpp"
+
+namespace ggq {
+
+constexpr int GT_BM = 256, GT_BN = 256, GT_BK = 32;
+constexpr int GT_WAVES = 8, GT_THREADS = GT_WAVES * 64;
+constexpr int GT_PITCH = GT_BK * 2;                      // bytes per tile row
+constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 KiB
+constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged span (8)
+
+GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) & 1u); }
+
+template <class F> struct GemmGeom {
+    using G = MfmaGeom<F>;
+    static constexpr int UNITS = GT_BN * G::U;                                   // 16-byte units of one staged span
+    static constexpr int NUW = (UNITS + GT_THREADS - 1) / GT_THREADS;            // units per thread
+    static constexpr int STAGING = NUW * GT_THREADS * 16;                        // LDS bytes (>= 256 * ROW_STRIDE)
+    static constexpr int LDS_BYTES = 4 * GT_TILE + STAGING;
+};
+
+template <class F, int OUT>
+__global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+                                                          const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
+                                                          uint32_t m, uint32_t n_rows, uint32_t cols, uint32_t tiles_m, uint32_t tiles_n)
+{
+    using G = MfmaGeom<F>;
+    using GG = GemmGeom<F>;
+    static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only");
+    constexpr int CPB = F::BS / 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const xt = smem;                        // X[0], X[1]
+    uint8_t* const wt = smem + 2 * GT_TILE;          // W[0], W[1]
+    uint8_t* const stg = smem + 4 * GT_TILE;
+
+    const uint32_t t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint32_t lane = t & 63u;
+
+    // ---- which tile: XCD x takes a contiguous eighth of the column-major tile list (tm fastest)
+    const uint32_t n_tiles = tiles_m * tiles_n;
+    uint32_t tile = blockIdx.x;
+    {
+        const uint32_t q = n_tiles >> 3, r = n_tiles & 7u, xcd = tile & 7u, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;       // bijective for any n_tiles
+    }
+    const uint32_t tn = tile / tiles_m, tm = tile - tn * tiles_m;
+    const uint32_t m0 = tm * GT_BM, n0 = tn * GT_BN;
+
+    const gcptr packed = (gcptr)packed_;
+    const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
+    const uint32_t n_spans = cols / MF_SPAN, n_steps = n_spans * GT_STEPS;
+
+    // ---- staging fill: unit u of the tile's span = (row u / U, 16-byte piece u % U); thread takes units t, t + 512, ...
+    auto fetch = [&](uint32_t span, u32x4 (&pf)[GG::NUW]) {
+#pragma unroll
+        for (int u = 0; u < GG::NUW; u++) {
+            const uint32_t unit = t + (uint32_t)(GT_THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
+            const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
+            const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
+            // the last unit of a row may reach past the row's span by < 16 bytes inside its aligned 16-byte unit: same page, never faults
+            pf[u] = (ur < (uint32_t)GT_BN && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage = [&](const u32x4 (&pf)[GG::NUW]) {
+#pragma unroll
+        for (int u = 0; u < GG::NUW; u++) *reinterpret_cast<u32x4*>(stg + (t + (uint32_t)(GT_THREADS * u)) * 16u) = pf[u];
+    };
+
+    // ---- weight decode: thread -> (row t / 2, chunks 2 (t & 1), 2 (t & 1) + 1 of the K-step)
+    const uint32_t drow = t >> 1, dc0 = (t & 1u) * 2u;
+    const uint32_t wrow = (n0 + drow < n_rows) ? n0 + drow : n_rows - 1;
+    const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
+    const uint32_t dswz = gt_swz(drow);
+    auto decode = [&](uint32_t step, uint8_t* wdst) {
+        const uint32_t span = step / GT_STEPS, ks = step % GT_STEPS;
+        const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
+        const uint8_t* wspan = stg + drow * (uint32_t)G::ROW_STRIDE + a;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
+            const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, (int)(j % CPB));
+            uint32_t w[4];
+            weights8<F, OUT>(f, w);
+            *reinterpret_cast<u32x4*>(wdst + drow * GT_PITCH + ((c ^ dswz) * 16u)) = u32x4{w[0], w[1], w[2], w[3]};
+        }
+    };
+
+    // ---- x tile: thread -> rows t / 4 and t / 4 + 128, 16-byte piece t % 4
+    const uint32_t xrow = t >> 2, xpc = t & 3u;
+    const GGQ_GLOBAL uint8_t* xsrc[2];
+    uint32_t xdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t row = xrow + 128u * (uint32_t)i, mr = m0 + row;
+        xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + xpc * 16u;
+        xdst[i] = row * GT_PITCH + ((xpc ^ gt_swz(row)) * 16u);
+    }
+    auto xload = [&](uint32_t step, u32x4 (&xr)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * GT_PITCH);
+    };
+    auto xstore = [&](const u32x4 (&xr)[2], uint8_t* xd) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) *reinterpret_cast<u32x4*>(xd + xdst[i]) = xr[i];
+    };
+
+    // ---- MFMA roles: wave -> (wm = wave / 4: rows of x [128 wm, +128), wn = wave % 4: output columns [64 wn, +64))
+    const uint32_t wm = (uint32_t)wave >> 2, wn = (uint32_t)wave & 3u;
+    const uint32_t r32 = lane & 31u, hk = lane >> 5, fswz = gt_swz(r32);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[nt][mt][i] = 0.0f;
+
+    auto mma = [&](const uint8_t* xs, const uint8_t* ws) {
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
+            u32x4 wa[2], xb[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + (128u * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
+        }
+    };
+
+    // ---- prologue: span 0 staged, tile 0 of both operands in buffer 0
+    u32x4 pf[GG::NUW];
+    u32x4 xr[2];
+    fetch(0u, pf);
+    xload(0u, xr);
+    stage(pf);
+    xstore(xr, xt);
+    __syncthreads();
+    if (n_spans > 1) fetch(1u, pf);
+    decode(0u, wt);
+    if (n_steps > 1) xload(1u, xr);
+    __syncthreads();
+
+    for (uint32_t step = 0; step < n_steps; step++) {
+        const uint32_t cur = step & 1u, nxt = cur ^ 1u;
+        const bool more = step + 1 < n_steps;
+        if (more && (step + 1) % GT_STEPS == 0) {
+            // the next K-step opens a new span: every decode of the old one finished before the previous barrier
+            stage(pf);
+            __syncthreads();
+            if ((step + 1) / GT_STEPS + 1 < n_spans) fetch((step + 1) / GT_STEPS + 1, pf);
+        }
+        if (more) decode(step + 1, wt + nxt * GT_TILE);
+        mma(xt + cur * GT_TILE, wt + cur * GT_TILE);
+        if (more) {
+            xstore(xr, xt + nxt * GT_TILE);
+            if (step + 2 < n_steps) xload(step + 2, xr);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, cast, transpose through LDS (wave-private 8 KiB: 64 rows of x  x  64 columns), full-line stores.
+    // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here
+    // row = output column n inside its 32-block, col = row of x inside its 32-block.
+    uint8_t* const ep = smem + wave * 8192;
+    const uint32_t nbase = n0 + 64u * wn, mbase = m0 + 128u * wm;
+    float bias[2][4][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t n = nbase + 32u * (uint32_t)nt + 8u * (uint32_t)q + 4u * hk;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float b = 0.0f;
+                if (bias_ != nullptr && n + (uint32_t)k < n_rows) {
+                    const uint16_t bb = *reinterpret_cast<const uint16_t*>(bias_ + (size_t)(n + (uint32_t)k) * 2);
+                    if constexpr (OUT == OUT_F16) b = (float)__builtin_bit_cast(_Float16, bb);
+                    else b = bits_f32((uint32_t)bb << 16);
+                }
+                bias[nt][q][k] = b;
+            }
+        }
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+#pragma unroll
+        for (int mh = 0; mh < 2; mh++) {
+            const int mt = 2 * rd + mh;
+            const uint32_t ml = 32u * (uint32_t)mh + r32;                            // row of x inside the 64-row round
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float v0 = acc[nt][mt][4 * q + 0] + bias[nt][q][0], v1 = acc[nt][mt][4 * q + 1] + bias[nt][q][1];
+                    const float v2 = acc[nt][mt][4 * q + 2] + bias[nt][q][2], v3 = acc[nt][mt][4 * q + 3] + bias[nt][q][3];
+                    u32x2 o;
+                    if constexpr (OUT == OUT_F16) o = u32x2{pack_f16(v0, v1), pack_f16(v2, v3)};
+                    else o = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                    const uint32_t p = 4u * (uint32_t)nt + (uint32_t)q;              // 16-byte piece = columns 8p .. 8p+7
+                    *reinterpret_cast<u32x2*>(ep + ml * 128u + ((p ^ (ml & 7u)) * 16u) + 8u * hk) = o;
+                }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t row = (lane >> 3) + 8u * (uint32_t)i, p = lane & 7u;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * 128u + ((p ^ (row & 7u)) * 16u));
+            const uint32_t mr = mbase + 64u * (uint32_t)rd + row, nc = nbase + 8u * p;
+            if (mr < m && nc < n_rows) gstore<false>((gptr)y_ + ((uint64_t)mr * n_rows + nc) * 2, v);       // n_rows % 8 == 0 (host)
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace ggq

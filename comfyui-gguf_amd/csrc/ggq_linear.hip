@@ -1,10 +1,12 @@
 // ggq_linear.hip -- C ABI over ggq_linear.hpp: y = x @ dequant(W)^T + bias for m <= 4 rows of x, from the packed blocks.
 #include "ggq_linear.hpp"
 #include "ggq_mfma.hpp"
+#include "ggq_gemm.hpp"
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -78,15 +80,47 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
-constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4, 8
-struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][log2 MB]
-#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_mfma<F, OUT, 8>}
+// ---- the shared-tile kernel (ggq_gemm.hpp): 256 rows of x  x  256 output columns per workgroup, weights decoded once per workgroup
+template <class F, int OUT>
+hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    constexpr uint32_t lds = (uint32_t)GemmGeom<F>::LDS_BYTES;
+    static_assert(lds <= 160 * 1024, "one workgroup's LDS");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<uint64_t> raised{0};          // > 64 KiB of dynamic LDS: raise the limit once per device for this instantiation
+    const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile<F, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const uint32_t tiles_m = (m + GT_BM - 1) / GT_BM, tiles_n = (rows + GT_BN - 1) / GT_BN;
+    hipLaunchKernelGGL((linear_tile<F, OUT>), dim3(tiles_m * tiles_n), dim3(GT_THREADS), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
+                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4 (K-split kernel), then the 256 x 256 shared-tile kernel
+struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][shape]
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>}
 #define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
     GGQ_MF(FmtQ2_K), GGQ_MF(FmtQ3_K), GGQ_MF(FmtQ4_K), GGQ_MF(FmtQ5_K), GGQ_MF(FmtQ6_K),
     GGQ_MF(FmtIQ4_NL), GGQ_MF(FmtIQ4_XS),
 };
+
+// rows of x from which the shared-tile kernel takes over (measurement knob GGQ_TILE_MIN_M, read once)
+uint32_t tile_min_m()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("GGQ_TILE_MIN_M");
+        const int x = (e && *e) ? atoi(e) : 0;
+        return x > 0 ? (uint32_t)x : 192u;
+    }();
+    return v;
+}
 
 }  // namespace
 
@@ -101,13 +135,15 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     if (rows == 0 || m == 0) return GGQ_OK;
     if (!packed || !x || !y) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
-    // tile_rows: rows of x per workgroup tile (32, 64, 128, 256); 0 = pick from m.  Measured on FLUX / T5 layer shapes
-    // (profiles/r02_mfma_linear_tile_sweep.txt): one 32-row block up to m = 32; 64-row tiles from there to m ~ 384 (two blocks share
-    // every decoded weight, and twice as many workgroups as with 128-row tiles); 128-row tiles beyond.
+    // tile_rows: rows of x per workgroup tile.  32 / 64 / 128 = the K-split kernel (ggq_mfma.hpp: every lane decodes its own MFMA operand,
+    // one decode per 32 / 64 / 128 rows of x); 256 = the shared-tile kernel (ggq_gemm.hpp: 256 x 256 output tile, weights decoded once per
+    // workgroup into LDS; needs rows % 8 == 0); 0 = pick from m: one 32-row block up to m = 32, 64-row tiles to m < GGQ_TILE_MIN_M, the
+    // shared-tile kernel from there on (profiles/r03_gemm_tile_bench.json).
     int shape;
-    if (tile_rows == 0) shape = m <= 32 ? 0 : (m < 384 ? 1 : 2);
+    if (tile_rows == 0) shape = m <= 32 ? 0 : ((m < tile_min_m() || rows % 8u != 0) ? (m < 384 ? 1 : 2) : 3);
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
+    if (shape == 3 && rows % 8u != 0) return GGQ_ERR_ARG;
     const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
     return err == hipSuccess ? GGQ_OK : hip_fail(err);
 }

@@ -70,3 +70,27 @@ def make_tensor_bytes(qtype, shape, seed=0, mode="nominal"):
     """Packed bytes (1-D uint8) for a logical tensor of ``shape``."""
     n = int(np.prod(shape))
     return make_blocks(qtype, n_blocks_for(qtype, n), seed=seed, mode=mode).reshape(-1)
+
+
+def device_blocks(qtype, n_blocks, device, seed, mode="nominal"):
+    """Packed bytes (1-D uint8 torch tensor) generated ON ``device`` -- a whole weight set is gigabytes, too slow to draw with
+    numpy on the host and push over PCIe: uniformly random bytes, scale fields overwritten with fp16 values of the same
+    distributions as :func:`make_blocks` modes "nominal" / "signed" (the values differ from make_blocks for the same seed:
+    another generator)."""
+    import torch
+    qtype = GGMLQuantizationType(int(qtype))
+    _, ts = GGML_QUANT_SIZES[qtype]
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    blocks = torch.randint(0, 256, (n_blocks, ts), dtype=torch.uint8, device=device, generator=g)
+    if mode == "raw" or n_blocks == 0:
+        return blocks.reshape(-1)
+    if mode not in ("nominal", "signed"):
+        raise ValueError(f"device_blocks: mode {mode!r}")
+    lo, hi = (1e-3, 2.1e-2) if qtype in LEGACY_QTYPES else (1e-4, 2e-3)
+    for off in SCALE_FIELDS[qtype]:
+        vals = (torch.rand(n_blocks, device=device, generator=g) * (hi - lo) + lo).to(torch.float16)
+        if mode == "signed":
+            vals = torch.where(torch.rand(n_blocks, device=device, generator=g) < 0.5, -vals, vals)
+        blocks[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
+    return blocks.reshape(-1)

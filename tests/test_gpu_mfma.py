@@ -27,7 +27,12 @@ def test_mfma_linear_against_fp64_reference(pkg, name, kind):
     # (rows, cols, m, bias, tile): ragged output columns (rows % 32), ragged rows of x (m % 32), one row, several tiles of x,
     # 1 .. 12 spans of K (fewer spans than waves; not a multiple of the 4-way split)
     for rows, cols, m, with_bias, tile in ((203, 3072, 1, True, 0), (17, 256, 40, False, 0), (64, 768, 33, True, 32), (96, 1024, 300, False, 64),
-                                           (333, 512, 129, True, 128), (40, 2304, 260, True, 256), (32, 1280, 96, False, 0)):
+                                           (333, 512, 129, True, 128), (40, 2304, 260, True, 256), (32, 1280, 96, False, 0),
+                                           # the shared-tile kernel (256 x 256 output tiles, ggq_gemm.hpp): several tiles both ways with ragged
+                                           # edges; exactly one tile and one span; 9 spans (the staging buffer is refilled 8 times) x 3 tiles of x;
+                                           # fewer output columns than one MFMA block; picked automatically from m
+                                           (520, 1024, 300, True, 256), (256, 256, 256, False, 256), (264, 2304, 513, True, 256), (8, 512, 1000, False, 256),
+                                           (304, 768, 200, True, 0)):
         blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
         w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
         x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
@@ -68,6 +73,17 @@ def test_exact_arithmetic_cases_are_bit_equal(pkg, name, kind):
         want = torch.from_numpy(exact).to(dtype)                                             # ONE rounding, as the kernel's store
         got = fn(x, w)
         assert torch.equal(got.cpu(), want), (name, kind, m)
+    # the shared-tile kernel: 2 x 2 tiles with ragged edges, 6 spans; a weight tile decoded twice, skipped or written to the wrong
+    # LDS column shows up as a wrong integer multiple of 2^-8
+    rows = 264
+    blocks = _exact_blocks(pkg, q, rows, cols, seed=78)
+    w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+    w64 = _dense_weight(q, blocks, kind, rows, cols)
+    x = torch.randint(-4, 5, (300, cols), device=DEV, generator=g).to(dtype)
+    x64 = x.double().cpu().numpy()
+    assert (np.abs(x64) @ np.abs(w64).T).max() < 2.0 ** 16
+    want = torch.from_numpy(x64 @ w64.T).to(dtype)
+    assert torch.equal(pkg.fused.linear_mfma(x, w, tile_rows=256).cpu(), want), (name, kind, "shared-tile kernel")
 
 
 def test_mfma_linear_limits(pkg):
@@ -84,6 +100,7 @@ def test_mfma_linear_limits(pkg):
                 lambda: pkg.fused.linear_mfma(x, mk(Q.Q4_K, (64, 512), patches=[("p", "k")])),
                 lambda: pkg.fused.linear_mfma(x.cpu(), w),
                 lambda: pkg.fused.linear_mfma(x, w, tile_rows=48),
+                lambda: pkg.fused.linear_mfma(x, mk(Q.Q4_K, (60, 512)), tile_rows=256),        # the shared-tile kernel needs rows % 8 == 0
                 lambda: pkg.fused.linear_mfma(x, w, tile_rows=-96)):
         with pytest.raises(GGQUnsupported):
             bad()
@@ -106,6 +123,8 @@ def test_mfma_randomized_sweep(pkg):
         rows, cols = int(rng.integers(1, 400)), 256 * int(rng.integers(1, 15))
         m = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 128, 129, 257, 700]))
         tile = int(rng.choice([0, 0, 32, 64, 128, 256]))
+        if tile == 256:
+            rows = (rows + 7) // 8 * 8                         # the shared-tile kernel stores 16 bytes (8 columns) per lane
         blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=1000 + case, mode="signed")
         w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
         x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
