@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -184,10 +184,21 @@ def build_fast(force=False):
     if not gcc or not inc or not os.path.exists(os.path.join(inc, "Python.h")):
         return None
     os.makedirs(LIB_DIR, exist_ok=True)
-    proc = subprocess.run([gcc, "-O2", "-shared", "-fPIC", "-I" + inc, FAST_SRC, "-o", out + ".tmp"], capture_output=True, text=True)
-    if proc.returncode:
-        raise GGQNativeError(f"gcc failed on ggq_pyfast.c:\n{proc.stderr[-2000:]}")
-    os.replace(out + ".tmp", out)
+    # a unique temporary name: several processes (one per GPU) may build at once; os.replace makes the last one win atomically
+    fd, tmp = tempfile.mkstemp(prefix="_ggq_fast.", suffix=".tmp", dir=LIB_DIR)
+    os.close(fd)
+    try:
+        proc = subprocess.run([gcc, "-O2", "-shared", "-fPIC", "-I" + inc, FAST_SRC, "-o", tmp], capture_output=True, text=True)
+        if proc.returncode:
+            # the binding is OPTIONAL (ctypes serves the same entry points): a compiler problem here must not fail the build of the product
+            import warnings
+            warnings.warn(f"comfyui-gguf_amd: gcc failed on ggq_pyfast.c, keeping the ctypes binding:\n{proc.stderr[-1000:]}")
+            return None
+        os.replace(tmp, out)
+        tmp = None
+    finally:
+        if tmp is not None and os.path.exists(tmp):
+            os.remove(tmp)
     return out
 
 
@@ -197,10 +208,17 @@ def fast():
     if not os.path.exists(path):
         return None
     import importlib.util
-    spec = importlib.util.spec_from_file_location("_ggq_fast", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    if os.path.getmtime(path) < os.path.getmtime(FAST_SRC):
+        return None                                            # stale against its source: ctypes until build() has refreshed it
+    try:
+        spec = importlib.util.spec_from_file_location("_ggq_fast", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    except (ImportError, OSError):
+        return None
     L = lib()
+    if getattr(mod, "ABI", None) != L.ggq_abi_version():
+        return None                                            # built against another ggq.h: raw function pointers with other signatures
     mod.bind(ctypes.cast(L.ggq_dequant, ctypes.c_void_p).value)
     mod.bind_linear(ctypes.cast(L.ggq_linear_small, ctypes.c_void_p).value, ctypes.cast(L.ggq_linear_mfma, ctypes.c_void_p).value)
     return mod

@@ -322,7 +322,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 8; }
+int ggq_abi_version(void) { return 9; }
 
 #ifndef GGQ_BUILD_ID
 #define GGQ_BUILD_ID "unstamped"

@@ -34,6 +34,8 @@
 
 #include "ggq_mfma.hpp"
 
+#include <type_traits>
+
 namespace ggq {
 
 constexpr int GT_BM = 256, GT_BN = 256, GT_BK = 32;
@@ -41,6 +43,12 @@ constexpr int GT_WAVES = 8, GT_THREADS = GT_WAVES * 64;
 constexpr int GT_PITCH = GT_BK * 2;                      // bytes per tile row
 constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 KiB
 constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged span (8)
+#ifndef GGQ_GT_SCHED
+#define GGQ_GT_SCHED 0      /* VALU instructions asked for behind every MFMA of a K-step (0 = leave the order to the compiler); A/B builds */
+#endif
+#ifndef GGQ_GT_PINGPONG
+#define GGQ_GT_PINGPONG 1   /* the two waves of a SIMD run decode and MFMAs in opposite order (0 = same order); A/B builds */
+#endif
 
 GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) & 1u); }
 
@@ -176,26 +184,60 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
     __syncthreads();
     if (n_spans > 1) fetch(1u, pf);
     decode(0u, wt);
-    if (n_steps > 1) xload(1u, xr);
+    xload(n_steps > 1 ? 1u : 0u, xr);
     __syncthreads();
 
-    for (uint32_t step = 0; step < n_steps; step++) {
-        const uint32_t cur = step & 1u, nxt = cur ^ 1u;
-        const bool more = step + 1 < n_steps;
-        if (more && (step + 1) % GT_STEPS == 0) {
+    // ---- main loop.  One K-step = [decode weight tile t+1 -> W[next]] + [MFMAs on X[cur], W[cur]] + [x registers -> X[next], loads of
+    // tile t+2] + one s_barrier.  decode(t + 1) and mma(t) are independent, so a wave may run them in either order: the two waves that
+    // share a SIMD (w and w + 4: a workgroup's waves are dealt to the four SIMDs cyclically) take OPPOSITE orders (PONG) -- one feeds the
+    // matrix pipe while the other keeps the VALU busy with the decode, then they swap; sched_barrier keeps the compiler from mixing the
+    // halves back together.  Each order is its own copy of the loop (a wave-uniform branch around the whole loop, not inside it: the
+    // 128 accumulator registers never meet in a phi); steps come in pairs so that the buffer parity is a compile-time constant.
+    auto kstep = [&](uint32_t step, auto parity_tag, auto pong_tag, auto decode_tag) {
+        constexpr int P = decltype(parity_tag)::value;
+        constexpr bool PONG = decltype(pong_tag)::value, DECODE = decltype(decode_tag)::value;
+        uint8_t* const xcur = xt + P * GT_TILE;
+        uint8_t* const wcur = wt + P * GT_TILE;
+        uint8_t* const xnxt = xt + (P ^ 1) * GT_TILE;
+        uint8_t* const wnxt = wt + (P ^ 1) * GT_TILE;
+        if (DECODE && (step + 1) % GT_STEPS == 0) {
             // the next K-step opens a new span: every decode of the old one finished before the previous barrier
+            const uint32_t span = (step + 1) / GT_STEPS;
             stage(pf);
             __syncthreads();
-            if ((step + 1) / GT_STEPS + 1 < n_spans) fetch((step + 1) / GT_STEPS + 1, pf);
+            if (span + 1 < n_spans) fetch(span + 1, pf);
         }
-        if (more) decode(step + 1, wt + nxt * GT_TILE);
-        mma(xt + cur * GT_TILE, wt + cur * GT_TILE);
-        if (more) {
-            xstore(xr, xt + nxt * GT_TILE);
-            if (step + 2 < n_steps) xload(step + 2, xr);
+        if constexpr (!DECODE) {
+            mma(xcur, wcur);
+        } else if constexpr (PONG && GGQ_GT_PINGPONG) {
+            mma(xcur, wcur);
+            __builtin_amdgcn_sched_barrier(0);
+            decode(step + 1, wnxt);
+        } else {
+            decode(step + 1, wnxt);
+#if GGQ_GT_PINGPONG
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            mma(xcur, wcur);
         }
+        // x tile of the next step: registers -> LDS; then the loads of the step after (clamped at the end: a harmless re-read)
+        xstore(xr, xnxt);
+        xload(step + 2 < n_steps ? step + 2 : n_steps - 1, xr);
         __syncthreads();
-    }
+    };
+    auto main_loop = [&](auto pong_tag) {
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, 1>;
+        uint32_t step = 0;
+        for (; step + 2 < n_steps; step += 2) {                     // n_steps is a multiple of 8
+            kstep(step, T0{}, pong_tag, std::true_type{});
+            kstep(step + 1, T1{}, pong_tag, std::true_type{});
+        }
+        kstep(step, T0{}, pong_tag, std::true_type{});
+        kstep(step + 1, T1{}, pong_tag, std::false_type{});        // the last step has nothing left to decode
+    };
+    if (wave >= 4) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
     // ---- epilogue: bias, cast, transpose through LDS (wave-private 8 KiB: 64 rows of x  x  64 columns), full-line stores.
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here

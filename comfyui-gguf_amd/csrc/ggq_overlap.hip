@@ -15,6 +15,13 @@
 namespace {
 constexpr int MAX_SLOTS = 16;
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// Under HIP-graph capture the overlap protocol cannot work (events recorded outside the capture, side streams that never rejoin it): the
+// entry points that touch the caller's stream refuse, the host side (overlap.py eligible()) does not even try.
+bool capturing(void* stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 }  // namespace
 
 struct ggq_overlap {
@@ -63,6 +70,10 @@ int ggq_overlap_copy(ggq_overlap* ov, int staging_slot, const void* host_packed,
         e = hipStreamWaitEvent(ov->copy, ov->consumed[staging_slot], 0);
         if (e == hipSuccess && split < packed_bytes) e = hipStreamWaitEvent(ov->copy2, ov->consumed[staging_slot], 0);
     }
+    // ... and the slot's previous COPY: a tenant that was staged but never unpacked (a mispredicted layer) leaves `consumed` stale, and its
+    // first half -- on `copy` -- may still be landing in the bytes this tenant's second half -- on `copy2` -- is about to write.  `copied` was
+    // recorded on `copy` after it had waited for that tenant's second half, so it covers both (waiting on a never-recorded event is a no-op).
+    if (e == hipSuccess && split < packed_bytes) e = hipStreamWaitEvent(ov->copy2, ov->copied[staging_slot], 0);
     if (e == hipSuccess && split) e = hipMemcpyAsync(dev_packed, host_packed, (size_t)split, hipMemcpyHostToDevice, ov->copy);
     if (e == hipSuccess && split < packed_bytes) {
         e = hipMemcpyAsync(static_cast<uint8_t*>(dev_packed) + split, static_cast<const uint8_t*>(host_packed) + split, (size_t)(packed_bytes - split),
@@ -82,6 +93,7 @@ int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int staging_slot, int qtype,
     if (out_dtype < 0 || out_dtype > 2 || compute_dtype < 0 || compute_dtype > 2) return GGQ_ERR_ARG;
     if (n_blocks && (!dev_packed || !out)) return GGQ_ERR_ARG;
     if (n_blocks && (!aligned16(dev_packed) || !aligned16(out))) return GGQ_ERR_ALIGN;
+    if (capturing(main_stream)) return GGQ_ERR_ARG;      // the side streams would be pulled into the capture and never joined back
     hipError_t e = hipEventRecord(ov->main_mark[slot], static_cast<hipStream_t>(main_stream));
     if (e == hipSuccess) e = hipStreamWaitEvent(ov->unpack, ov->main_mark[slot], 0);
     if (e == hipSuccess && staging_slot >= 0) e = hipStreamWaitEvent(ov->unpack, ov->copied[staging_slot], 0);
@@ -99,6 +111,7 @@ int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int staging_slot, int qtype,
 int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream)
 {
     if (!ov || slot < 0 || slot >= ov->n_slots) return GGQ_ERR_ARG;
+    if (capturing(main_stream)) return GGQ_ERR_ARG;      // `done` was recorded outside the capture
     const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), ov->done[slot], 0);
     return e == hipSuccess ? GGQ_OK : ggq::hip_fail(e);
 }

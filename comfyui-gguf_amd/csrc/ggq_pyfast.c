@@ -118,4 +118,17 @@ static PyMethodDef fast_methods[] = {
 
 static struct PyModuleDef fast_module = {PyModuleDef_HEAD_INIT, "_ggq_fast", "fast binding of ggq_dequant", -1, fast_methods, NULL, NULL, NULL, NULL};
 
-PyMODINIT_FUNC PyInit__ggq_fast(void) { return PyModule_Create(&fast_module); }
+/* ABI: the version of include/ggq.h whose three signatures this file was written against.  _native.fast() refuses a binary whose
+ * constant differs from the loaded library's ggq_abi_version(): a stale _ggq_fast would call through raw pointers with the wrong
+ * argument lists. */
+#define GGQ_FAST_ABI 9
+
+PyMODINIT_FUNC PyInit__ggq_fast(void)
+{
+    PyObject* m = PyModule_Create(&fast_module);
+    if (m != NULL && PyModule_AddIntConstant(m, "ABI", GGQ_FAST_ABI) < 0) {
+        Py_DECREF(m);
+        return NULL;
+    }
+    return m;
+}

@@ -69,7 +69,11 @@ def _prepare(x, weight, bias, dequant_dtype, what, dtypes, need_cols_256):
     return ent[0], rows, cols, m, xf, bias
 
 
-def _run(call, name, qid, weight, rows, cols, xf, m, bias, x, extra):
+def _run(call, name, qid, weight, rows, cols, xf, m, bias, x, extra, weight_to=None):
+    if weight_to is not None and weight.device != x.device:
+        # low-VRAM mode (CPU-resident packed weight, reference ops.py:209): the host -> device copy is made HERE, after every
+        # eligibility check has passed -- a request the kernel declines never pays for a copy the reference's method then repeats
+        weight = weight.to(weight_to)
     with torch._C.DisableTorchFunctionSubclass():
         if not weight.is_cuda or weight.dtype is not torch.uint8 or not weight.is_contiguous() or weight.data_ptr() & 15:
             raise GGQUnsupported("packed weight must be a contiguous, 16-byte aligned byte tensor on the GPU")
@@ -90,23 +94,32 @@ def _run(call, name, qid, weight, rows, cols, xf, m, bias, x, extra):
     return y if x.dim() == 2 else y.reshape(*x.shape[:-1], rows)
 
 
-def linear_small(x, weight, bias=None, dequant_dtype=None):
+_LIN_SLICE, _LIN_WAVES = 6 * 64 * 16, 4        # csrc/ggq_linear.hpp LIN_SLICE / LIN_WAVES: one row's packed bytes must fit a wave's LDS slice
+
+
+def linear_small(x, weight, bias=None, dequant_dtype=None, weight_to=None):
     """x: (..., cols) on the GPU with at most MAX_ROWS rows in total; weight: GGMLTensor of logical shape (rows, cols).
+    ``weight_to``: device to move a CPU-resident packed weight to once the request is known to be served (install.py).
     Raises GGQUnsupported for anything the kernel does not take (the caller keeps dequantize + F.linear)."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused linear", _OUT_CODE, False)
     if not 1 <= m <= MAX_ROWS:
         raise GGQUnsupported(f"fused linear takes 1..{MAX_ROWS} input rows, got {m}")
+    _, block_size, type_size = _HIP_TABLE[_qtype_key(qid)]
+    if cols % block_size or cols // block_size * type_size + 15 > _LIN_SLICE or m * cols * x.element_size() + _LIN_WAVES * _LIN_SLICE > 150 * 1024:
+        raise GGQUnsupported("fused linear: a row's packed bytes (or x) exceed the kernel's LDS staging")     # what ggq_linear_small answers GGQ_ERR_ARG to
     if _small_call is None:
         _bind()
-    return _run(_small_call, "ggq_linear_small", qid, weight, rows, cols, xf, m, bias, x, ())
+    return _run(_small_call, "ggq_linear_small", qid, weight, rows, cols, xf, m, bias, x, (), weight_to)
 
 
-def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0):
+def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None):
     """``F.linear(x, dequantize_tensor(weight, x.dtype), bias)`` for any number of rows of x, on the matrix cores, from the packed
     blocks (include/ggq.h ``ggq_linear_mfma``).  x: (..., cols) fp16 / bf16 on the GPU; weight: GGMLTensor of logical shape
     (rows, cols) with cols % 256 == 0.  Weights bit-identical to the reference's; fp32 accumulation in the kernel's own order
     (tolerance parity, tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
+    if tile_rows not in (0, 32, 64, 128, 256) or (tile_rows == 256 and rows % 8):
+        raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 32, 64, 128 or 256 (the shared-tile kernel, rows % 8 == 0)")
     if _mfma_call is None:
         _bind()
-    return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),))
+    return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)

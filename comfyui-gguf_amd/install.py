@@ -169,10 +169,12 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
             cols = input.shape[-1]
             m = input.numel() // cols if cols else 0
             try:
+                # a CPU-resident weight (low-VRAM mode) is copied to the GPU only once the kernel is known to take the request
+                # (weight_to): a declined request costs no copy, the reference's method below makes its own (ops.py:209)
                 if small_m and m <= MAX_ROWS:
-                    return linear_small(input, weight.to(input.device), self.bias, self.dequant_dtype)
+                    return linear_small(input, weight, self.bias, self.dequant_dtype, weight_to=input.device)
                 if m <= mfma_max_m:
-                    return linear_mfma(input, weight.to(input.device), self.bias, self.dequant_dtype)
+                    return linear_mfma(input, weight, self.bias, self.dequant_dtype, weight_to=input.device)
             except unsupported:
                 pass
         return reference_forward(self, input)

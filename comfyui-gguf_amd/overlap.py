@@ -22,8 +22,9 @@ What it changes for the caller, and why it is opt-in (``install(..., overlap=Tru
   * the dense weight handed to ``F.linear`` is a view into a scratch buffer that is rewritten two layers later.  The reference's
     layers consume the weight immediately (ops.py:242-271), so nothing notices -- but code that stashes the result of
     ``cast_bias_weight`` would;
-  * low-VRAM mode keeps a PINNED host copy of every packed weight it has seen (the async copy needs page-locked memory): host RAM
-    of the size of the packed model (6.8 GB for FLUX.1-dev Q4_K_M);
+  * low-VRAM mode keeps a PINNED host copy of the packed weight of every LIVE layer module it has seen (the async copy needs page-locked
+    memory): host RAM of the size of the packed models currently loaded (6.8 GB for FLUX.1-dev Q4_K_M).  The copies are tied to the
+    modules by weak references: a model that is unloaded gives its pinned memory back (``stats()["pinned_host_bytes"]``);
   * 2 x the largest dense weight of scratch per device (2 x 132 MB for FLUX.1-dev in bf16), plus 3 x the largest packed weight of
     staging in low-VRAM mode (3 x 37 MB).
 LoRA-patched weights (patched in place, ops.py:183-190), non-quantized weights, dtypes the kernels do not emit, tracing under
@@ -48,7 +49,34 @@ class _Slot:
 
     def __init__(self):
         self.dense = None         # uint8 scratch on the device, grown to the largest dense weight seen
-        self.owner = None         # id(module) whose prefetched weight currently lives here
+        self.owner = None         # weak reference to the module whose prefetched weight currently lives here
+
+
+class _ModuleState:
+    """Everything the prefetcher remembers about ONE layer module.  Lives in a WeakKeyDictionary keyed by the module itself, so it
+    dies with the module (a model that is unloaded takes its pinned host copies, its learnt successor and its pending prefetch
+    with it) and a recycled ``id()`` can never inherit it.  The pinned buffer is not freed on the spot: a raw-stream copy that
+    torch's host allocator knows nothing about may still be reading it, so it is handed to the prefetcher's ``_retired`` list,
+    which is emptied behind a device synchronisation."""
+    __slots__ = ("next", "last", "pinned", "pending", "_retired", "__weakref__")
+
+    def __init__(self, retired):
+        self.next = None          # weak reference to the module that was called after this one last time
+        self.last = None          # (dtype, device index) of its last call
+        self.pinned = None        # (weak reference to the CPU weight object, its version, pinned uint8 copy)
+        self.pending = None       # (weight ref, version, dtype, compute dtype, device index, slot index, dense view)
+        self._retired = retired
+
+    def retire_pinned(self):
+        if self.pinned is not None:
+            self._retired.append(self.pinned[2])
+            self.pinned = None
+
+    def __del__(self):
+        try:
+            self.retire_pinned()
+        except Exception:
+            pass
 
 
 class _Staging:
@@ -89,10 +117,8 @@ class LayerPrefetcher:
         # costs about as much twice per layer, and the unpack's streaming traffic disturbs the GEMM's cache residency.
         self.resident = bool(resident)
         self._devices = {}
-        self._next = {}            # id(module) -> weakref to the module that was called after it last time
-        self._last = {}            # id(module) -> (dtype, device index, dequant_dtype) of its last call
-        self._pinned = {}          # id(module) -> (weakref to the CPU weight object, version, pinned uint8 copy)
-        self._pending = {}         # id(module) -> (weight object ref, version, dtype, compute dtype, device index, slot index, dense view)
+        self._state = weakref.WeakKeyDictionary()     # module -> _ModuleState (weak keys: nothing here keeps a module, or what it pinned, alive)
+        self._retired = []         # pinned host buffers whose owner died or was replaced; freed behind a device sync (_drain_retired)
         self._prev = None          # weakref to the module of the previous call
         self._owner_thread = None
         self.hits = self.misses = self.mispredicted = self.bypassed = 0
@@ -114,6 +140,10 @@ class LayerPrefetcher:
             self._owner_thread = tid
         if tid != self._owner_thread or _dq._is_compiling():
             return False
+        if torch.cuda.is_current_stream_capturing():
+            # under HIP-graph capture the side streams would be pulled into the capture without ever joining it back, and the
+            # main stream would wait on events recorded outside of it: the capture takes the reference's single-stream path
+            return False
         index = torch.device(device).index
         index = torch.cuda.current_device() if index is None else index
         return bool(_dq._DEVICE_OK.get(index) or _dq._device_served(index))
@@ -123,6 +153,20 @@ class LayerPrefetcher:
         self.bypassed += 1
 
     # ---- internals
+    def _st(self, module):
+        st = self._state.get(module)
+        if st is None:
+            st = self._state[module] = _ModuleState(self._retired)
+        return st
+
+    def _drain_retired(self):
+        """Free the pinned buffers of dead / replaced weights -- after everything in flight on the devices (the raw copy streams
+        included) is done with them.  Runs once per model unload, not per call."""
+        if self._retired:
+            for index in list(self._devices):
+                torch.cuda.synchronize(index)
+            del self._retired[:]
+
     def _dev(self, index):
         d = self._devices.get(index)
         if d is None:
@@ -136,14 +180,16 @@ class LayerPrefetcher:
 
     def _host_bytes(self, module, w):
         """Pinned copy of a CPU-resident packed weight (made once per weight object and version)."""
-        ent = self._pinned.get(id(module))
+        st = self._st(module)
+        ent = st.pinned
         if ent is not None and ent[0]() is w and ent[1] == w._version:
             return ent[2]
+        st.retire_pinned()                                    # another weight object / version: the old copy may still be in flight
         with _dq._NoTorchFunction():
             flat = _dq._as_bytes(w, align=False)
             pinned = torch.empty(flat.numel(), dtype=torch.uint8, pin_memory=True)
             pinned.copy_(flat)
-        self._pinned[id(module)] = (weakref.ref(w), w._version, pinned)
+        st.pinned = (weakref.ref(w), w._version, pinned)
         return pinned
 
     def _stage_copy(self, module, index):
@@ -202,7 +248,7 @@ class LayerPrefetcher:
                 if staging_index is None:
                     return False
                 data = dev.staging[staging_index].packed
-                nbytes = self._pinned[id(module)][2].numel()
+                nbytes = self._st(module).pinned[2].numel()
             else:
                 staging_index = -1
                 if w.device.index != index:
@@ -225,15 +271,18 @@ class LayerPrefetcher:
                 with torch.cuda.device(index):
                     slot.dense = torch.empty(dense_bytes, dtype=torch.uint8, device=f"cuda:{index}")
             dense = slot.dense[:dense_bytes].view(dtype).view(shape)
-            if slot.owner is not None:
-                self._pending.pop(slot.owner, None)       # whatever lived in this slot is about to be overwritten
+            prev_owner = slot.owner() if slot.owner is not None else None
+            if prev_owner is not None and prev_owner is not module:
+                pst = self._state.get(prev_owner)
+                if pst is not None and pst.pending is not None and pst.pending[5] == slot_index:
+                    pst.pending = None                    # whatever lived in this slot is about to be overwritten
             with torch.cuda.device(index):
                 rc = _native.lib().ggq_overlap_prefetch(dev.handle, slot_index, staging_index, qid, data.data_ptr(), n_blocks, dense.data_ptr(),
                                                         compute_code, _dq._OUT_CODE[dtype], main_stream)
         _native.check(rc, "ggq_overlap_prefetch")
-        slot.owner = id(module)
+        slot.owner = weakref.ref(module)
         dev.turn = (slot_index + 1) % N_SLOTS
-        self._pending[id(module)] = (weakref.ref(w), w._version, dtype, compute, index, slot_index, dense)
+        self._st(module).pending = (weakref.ref(w), w._version, dtype, compute, index, slot_index, dense)
         return True
 
     # ---- the call
@@ -242,9 +291,11 @@ class LayerPrefetcher:
         index = torch.device(device).index
         index = _dq._cur_device() if index is None else index
         main_stream = _dq._raw_stream(index)
-        key = id(module)
+        if self._retired:
+            self._drain_retired()
+        st = self._st(module)
         w = module.weight
-        pend = self._pending.pop(key, None)
+        pend, st.pending = st.pending, None
         dense, used_slot = None, None
         if pend is not None:
             wref, version, p_dtype, p_compute, p_index, slot_index, p_dense = pend
@@ -255,7 +306,8 @@ class LayerPrefetcher:
                 self.hits += 1
             else:
                 self.mispredicted += 1
-            if dev.slots[slot_index].owner == key:
+            owner = dev.slots[slot_index].owner
+            if owner is not None and owner() is module:
                 dev.slots[slot_index].owner = None
         if dense is None:
             dense = compute_now()
@@ -263,28 +315,37 @@ class LayerPrefetcher:
         # learn the order, then look one layer ahead
         prev = self._prev() if self._prev is not None else None
         if prev is not None:
-            self._next[id(prev)] = weakref.ref(module)
+            self._st(prev).next = weakref.ref(module)
         self._prev = weakref.ref(module)
-        self._last[key] = (dtype, index)
-        nref = self._next.get(key)
-        nxt = nref() if nref is not None else None
+        st.last = (dtype, index)
+        nxt = st.next() if st.next is not None else None
         if nxt is not None:
-            if id(nxt) not in self._pending:
-                last = self._last.get(id(nxt))
-                if last is not None and last[1] == index:
-                    self._schedule(nxt, last[0], index, main_stream, avoid_slot=used_slot)
-            # low-VRAM mode: the layer after the next one starts its PCIe copy now, so the link never idles behind the unpack
-            n2ref = self._next.get(id(nxt))
-            nxt2 = n2ref() if n2ref is not None else None
-            if nxt2 is not None and nxt2 is not module and id(nxt2) in self._last:
-                self._stage_copy(nxt2, index)
+            nst = self._state.get(nxt)
+            if nst is not None:
+                if nst.pending is None and nst.last is not None and nst.last[1] == index:
+                    self._schedule(nxt, nst.last[0], index, main_stream, avoid_slot=used_slot)
+                # low-VRAM mode: the layer after the next one starts its PCIe copy now, so the link never idles behind the unpack
+                nxt2 = nst.next() if nst.next is not None else None
+                if nxt2 is not None and nxt2 is not module:
+                    n2st = self._state.get(nxt2)
+                    if n2st is not None and n2st.last is not None:
+                        self._stage_copy(nxt2, index)
         return dense
 
     def stats(self):
         return {"hits": self.hits, "misses": self.misses, "mispredicted": self.mispredicted, "bypassed": self.bypassed,
-                "pinned_host_bytes": sum(e[2].numel() for e in self._pinned.values()),
-                "scratch_bytes": sum(sum(s.dense.numel() for s in d.slots if s.dense is not None) + sum(s.packed.numel() for s in d.staging if s.packed is not None)
-                                     for d in self._devices.values())}
+                "modules_tracked": len(self._state),
+                "pinned_host_bytes": sum(st.pinned[2].numel() for st in list(self._state.values()) if st.pinned is not None),
+                "retired_host_bytes": sum(t.numel() for t in self._retired),
+                "scratch_bytes": self.scratch_bytes()}
+
+    def scratch_bytes(self, index=None):
+        """Device memory this prefetcher holds outside of what the reference's VRAM estimate knows about (dense scratch slots +
+        packed staging slots), in bytes; ``index``: one device, default all.  INTEGRATION.md section 5 shows where a maintainer adds
+        it to the ``temp.weight`` reservation of ``ggml_save_to_state_dict`` (reference ops.py:153-158)."""
+        devs = self._devices.values() if index is None else [d for i, d in self._devices.items() if i == index]
+        return sum(sum(s.dense.numel() for s in d.slots if s.dense is not None) + sum(s.packed.numel() for s in d.staging if s.packed is not None)
+                   for d in devs)
 
     def close(self):
         for index in list(self._devices):
@@ -292,10 +353,10 @@ class LayerPrefetcher:
         for d in self._devices.values():
             d.close()
         self._devices.clear()
-        self._pending.clear()
-        self._pinned.clear()
-        self._next.clear()
-        self._last.clear()
+        for st in list(self._state.values()):
+            st.pinned = None                                   # everything was synchronised above: nothing reads the pinned copies any more
+        self._state = weakref.WeakKeyDictionary()
+        del self._retired[:]
         self._prev = None
 
 

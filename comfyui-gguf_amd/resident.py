@@ -21,10 +21,13 @@ tensor's in-place version counter (a ``copy_`` into the packed bytes invalidates
 
 Low-VRAM mode (weights kept on the CPU, ``s.weight.to(device)`` on every forward, ops.py:209): ``GGMLTensor.to`` hands out
 a NEW tensor object per forward (ops.py:57-62), so nothing can ever hit -- every entry dies, unused, with the temporary it
-was keyed on.  The cache notices (``EPHEMERAL_STREAK`` entries in a row that died without a single hit) and stands aside:
-it stops inserting and only probes every ``PROBE_EVERY``-th call, so that mode pays one integer compare per call instead of
-the bookkeeping.  Any hit ends the streak.  (A packed byte address is not a usable key there: the caching allocator recycles
-the addresses of those temporaries between layers.)
+was keyed on, within the very call chain that created it.  The cache notices (``EPHEMERAL_STREAK`` entries in a row that died
+without a single hit AND within ``EPHEMERAL_WINDOW`` cache calls of their insertion) and stands aside: it stops inserting and
+only probes every ``PROBE_EVERY``-th call, so that mode pays one integer compare per call instead of the bookkeeping.  Any hit
+ends the streak.  A RESIDENT model that runs one forward and is then freed (a text encoder that encodes once and is unloaded)
+also dies without hits, but many calls after its entries were made: those deaths do not count, so the next model is cached from
+its first layer.  ``stats()["standing_aside"]`` reports the state.  (A packed byte address is not a usable key for the
+temporaries: the caching allocator recycles their addresses between layers.)
 """
 import collections
 import weakref
@@ -33,6 +36,7 @@ import torch
 
 
 EPHEMERAL_STREAK = 16      # entries in a row that died without a hit -> the callers hand in per-call temporaries
+EPHEMERAL_WINDOW = 8        # ... counted only when the entry died within this many cache calls of its insertion (a per-call temporary)
 PROBE_EVERY = 64           # ... then only every 64th cacheable call is inserted, to notice when that changes
 
 
@@ -41,7 +45,8 @@ class DenseCache:
         self.budget = int(budget_bytes)
         self._fn = dequantize_tensor
         self._require_gpu = require_gpu               # False only in the CPU unit tests of the bookkeeping
-        self._entries = collections.OrderedDict()     # key -> [weakref to packed tensor, version, dense, hits]
+        self._entries = collections.OrderedDict()     # key -> [weakref to packed tensor, version, dense, hits, call number of the insertion]
+        self._calls = 0                               # cacheable calls so far (the clock of EPHEMERAL_WINDOW)
         self.bytes = 0
         self.hits = self.misses = self.bypassed = self.ephemeral_bypassed = 0
         self._streak = 0                              # consecutive entries that died with their tensor, never hit
@@ -59,7 +64,10 @@ class DenseCache:
     def _tensor_died(self, key):
         ent = self._entries.get(key)
         if ent is not None:
-            self._streak = self._streak + 1 if ent[3] == 0 else 0
+            if ent[3] > 0:
+                self._streak = 0
+            elif self._calls - ent[4] <= EPHEMERAL_WINDOW:
+                self._streak += 1                      # a per-call temporary (low-VRAM mode); an unused entry that lived longer says nothing
         self._drop(key)
 
     def clear(self):
@@ -73,6 +81,7 @@ class DenseCache:
                 or getattr(tensor, "patches", None) or (self._require_gpu and not tensor.is_cuda)):
             self.bypassed += 1
             return self._fn(tensor, dtype, dequant_dtype)
+        self._calls += 1
         key = (id(tensor), dtype, dequant_dtype)
         ent = self._entries.get(key)
         if ent is not None:
@@ -98,10 +107,14 @@ class DenseCache:
         while self.bytes + size > self.budget and self._entries:
             self._drop(next(iter(self._entries)))      # least recently used first
         ref = weakref.ref(tensor, lambda _r, k=key: self._tensor_died(k))
-        self._entries[key] = [ref, tensor._version, dense, 0]
+        self._entries[key] = [ref, tensor._version, dense, 0, self._calls]
         self.bytes += size
         return dense
 
     def stats(self):
         return {"entries": len(self._entries), "bytes": self.bytes, "hits": self.hits, "misses": self.misses, "bypassed": self.bypassed,
-                "ephemeral_bypassed": self.ephemeral_bypassed}
+                "ephemeral_bypassed": self.ephemeral_bypassed, "standing_aside": self._streak >= EPHEMERAL_STREAK}
+
+    def scratch_bytes(self):
+        """Device memory the cache holds that the reference's VRAM estimate knows nothing about."""
+        return self.bytes

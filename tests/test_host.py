@@ -303,7 +303,20 @@ def test_dense_cache_bookkeeping(pkg):
     n = cache.stats()["ephemeral_bypassed"]
     other = mk()
     cache(other, torch.float16)
-    assert cache.stats()["entries"] == 2 and cache.stats()["ephemeral_bypassed"] == n
+    assert cache.stats()["entries"] == 2 and cache.stats()["ephemeral_bypassed"] == n and not cache.stats()["standing_aside"]
+    # a RESIDENT model that runs ONE forward and is then freed (a text encoder encoded once, then unloaded): all of its entries die
+    # without a hit too -- but long after they were made, not within the call that made them.  That must not make the cache stand aside
+    # for the next model.
+    cache2 = R.DenseCache(1 << 30, fake, require_gpu=False)
+    model = [mk() for _ in range(R.EPHEMERAL_STREAK + 8)]
+    for t in model:
+        cache2(t, torch.float16)
+    del model, t
+    gc.collect()
+    assert cache2.stats()["entries"] == 0 and not cache2.stats()["standing_aside"]
+    nxt = mk()
+    cache2(nxt, torch.float16)
+    assert cache2(nxt, torch.float16) is cache2(nxt, torch.float16) and cache2.stats()["ephemeral_bypassed"] == 0
 
 
 @pytest.mark.skipif(not reference.available(), reason="reference sources neither live nor staged")
