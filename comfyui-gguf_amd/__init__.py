@@ -13,6 +13,7 @@ fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
     resident    opt-in cache that keeps dequantized weights resident in HBM (288 GB make it possible)
     fused       opt-in fused dequantize + linear for inputs of one to four rows (modulation layers)
     overlap     opt-in side-stream prefetch: layer i+1's (host->device copy and) unpack under layer i's GEMM
+    lookahead   opt-in: the next layers' unpacks ride in the launch of the one that was asked for (one launch per K layers)
     sharding    tensor-list partitioning for one-process-per-GPU runs (no collectives)
     ops         GGMLTensor / GGMLLinear stand-ins for driving the path without ComfyUI
     manifests   synthetic weight manifests of the BASELINE.json configurations
@@ -23,7 +24,7 @@ from . import qtypes, synth  # noqa: F401  (torch-free)
 from .qtypes import GGMLQuantizationType, GGML_QUANT_SIZES  # noqa: F401
 
 __version__ = "0.1.0"
-_LAZY = ("_native", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap")
+_LAZY = ("_native", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap", "lookahead")
 
 
 def __getattr__(name):

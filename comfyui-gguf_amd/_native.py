@@ -31,6 +31,7 @@ _FMA_RE = re.compile(r"\b(v_(?:pk_)?(?:fma|fmac)_\w+|v_mad_(?:f16|f32|legacy_f\w
 
 GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM, GGQ_ERR_IO, GGQ_ERR_FORMAT = range(8)
 F16, BF16, F32 = 0, 1, 2          # ggq_dtype: compute and out dtypes
+BATCH_MAX = 32                    # GGQ_BATCH_MAX (include/ggq.h): tensors per ggq_dequant_batch call
 OUT_F16, OUT_BF16, OUT_F32 = F16, BF16, F32
 
 # every symbol include/ggq.h declares: name -> (restype, argtypes)
@@ -69,6 +70,7 @@ SYMBOLS = {
     "ggq_build_id": (ctypes.c_char_p, []),
     "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
+    "ggq_dequant_batch": (_int, [ctypes.POINTER(ggq_desc), _u32, _vp]),
     "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),
     "ggq_plan_launch": (_int, [_vp, _vp]),
     "ggq_plan_bytes": (_u64, [_vp]),

@@ -176,6 +176,7 @@ constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
 typedef hipError_t (*rows_fn)(const void*, const int64_t*, void*, uint64_t, uint32_t, uint64_t, hipStream_t);
+typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 
 // Single tensors of layer size (per-layer calls, ops.py:177; rocprof kernel times of 3072x3072 / 3072x12288 tensors, solo vs coop
 // builds): the coop shape is 3-8 % FASTER for the 4/5-bit formats (Q4_K 6.10 vs 6.61 us, 17.7 vs 18.1 us) but 3-8 % SLOWER for
@@ -233,6 +234,19 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     return hipGetLastError();
 }
 
+// a few tensors, descriptors by value: the whole-model team shape (the batch is several layers: 50-250 M elements)
+template <class F, int ARITH, int OUT>
+hipError_t run_few(const Few& few, uint32_t n, uint64_t groups, hipStream_t s)
+{
+    using T = TuneFor<F, ARITH, OUT>;
+    if (groups == 0) return hipSuccess;
+    const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
+    if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
+                       xrun_of<T, F>(groups));
+    return hipGetLastError();
+}
+
 // the embedding lookup: a few hundred rows of one table per call -- one-wave teams, plain loads (a token may repeat)
 template <class F, int ARITH, int OUT>
 hipError_t run_rows(const void* packed, const int64_t* indices, void* out, uint64_t n_rows, uint32_t row_blocks, uint64_t n_indices, hipStream_t s)
@@ -257,6 +271,7 @@ struct FormatEntry {
     one_fn one[3][3];      // [compute dtype][out dtype]
     many_fn many[3][3];
     rows_fn rows[3][3];
+    few_fn few[3][3];
 };
 
 #define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
@@ -266,7 +281,8 @@ struct FormatEntry {
         F::ID, F::BS, F::TS, {GGQ_GROUPS(F, AR_F16), GGQ_GROUPS(F, AR_BF16), GGQ_GROUPS(F, AR_F32)},     \
         {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
         {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)},   \
-        {GGQ_ROW(run_rows, F, AR_F16), GGQ_ROW(run_rows, F, AR_BF16), GGQ_ROW(run_rows, F, AR_F32)}    \
+        {GGQ_ROW(run_rows, F, AR_F16), GGQ_ROW(run_rows, F, AR_BF16), GGQ_ROW(run_rows, F, AR_F32)},   \
+        {GGQ_ROW(run_few, F, AR_F16), GGQ_ROW(run_few, F, AR_BF16), GGQ_ROW(run_few, F, AR_F32)}       \
     }
 
 const FormatEntry FORMATS[] = {
@@ -386,6 +402,47 @@ int ggq_dequant_rows(int qtype, const void* packed, uint64_t n_rows, uint32_t ro
     if (!aligned16(packed) || !aligned16(out)) return GGQ_ERR_ALIGN;        // the table and the result; rows start wherever their blocks do
     const hipError_t e = f->rows[compute_dtype][out_dtype](packed, indices, out, n_rows, row_blocks, n_indices, static_cast<hipStream_t>(hip_stream));
     return e == hipSuccess ? GGQ_OK : hip_fail(e);
+}
+
+int ggq_dequant_batch(const ggq_desc* descs, uint32_t n, void* hip_stream)
+{
+    if (n > 0 && !descs) return GGQ_ERR_ARG;
+    if (n > GGQ_BATCH_MAX) return GGQ_ERR_ARG;
+    const FormatEntry* fmt[GGQ_BATCH_MAX];
+    for (uint32_t i = 0; i < n; i++) {
+        fmt[i] = find_format(descs[i].qtype);
+        const int rc = check_tensor(fmt[i], descs[i].packed, descs[i].out, descs[i].n_blocks, descs[i].compute_dtype, descs[i].out_dtype);
+        if (rc != GGQ_OK) return rc;                     // nothing has been launched yet
+    }
+    bool done[GGQ_BATCH_MAX] = {};
+    for (uint32_t i = 0; i < n; i++) {
+        if (done[i]) continue;
+        // every not-yet-launched tensor of descs[i]'s (format, arithmetic, output dtype), in the caller's order, FEW_MAX per launch
+        Few few;
+        uint32_t k = 0;
+        uint64_t groups = 0;
+        const int cd = descs[i].compute_dtype, od = descs[i].out_dtype;
+        auto flush = [&]() -> hipError_t {
+            const hipError_t e = k ? fmt[i]->few[cd][od](few, k, groups, static_cast<hipStream_t>(hip_stream)) : hipSuccess;
+            k = 0;
+            groups = 0;
+            return e;
+        };
+        for (uint32_t j = i; j < n; j++) {
+            if (done[j] || fmt[j] != fmt[i] || descs[j].compute_dtype != cd || descs[j].out_dtype != od) continue;
+            done[j] = true;
+            if (descs[j].n_blocks == 0) continue;
+            few.d[k++] = Desc{static_cast<const uint8_t*>(descs[j].packed), static_cast<uint8_t*>(descs[j].out), descs[j].n_blocks, groups};
+            groups += (descs[j].n_blocks + fmt[i]->group[cd][od] - 1) / fmt[i]->group[cd][od];
+            if (k == (uint32_t)FEW_MAX) {
+                const hipError_t e = flush();
+                if (e != hipSuccess) return hip_fail(e);
+            }
+        }
+        const hipError_t e = flush();
+        if (e != hipSuccess) return hip_fail(e);
+    }
+    return GGQ_OK;
 }
 
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)

@@ -717,6 +717,25 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
     });
 }
 
+// a FEW tensors of one format, descriptors BY VALUE in the kernel arguments (no device table to build or keep): the next layers' unpacks
+// coalesced into one launch by the host (ggq_dequant_batch: the per-layer call chain of reference ops.py:177 looked a few layers ahead).
+// Finding the tensor of group g is a scan over at most FEW_MAX scalar-loaded first_group values.
+constexpr int FEW_MAX = 8;
+struct Few { Desc d[FEW_MAX]; };
+
+template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
+__global__ __launch_bounds__(WAVES * 64) void dequant_few(Few few, uint32_t n, uint64_t total_groups, uint32_t xrun_log2)
+{
+    Engine<F, G, OUT, NTL, NTS, WAVES, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
+        uint32_t lo = 0;
+#pragma unroll
+        for (int i = 1; i < FEW_MAX; i++)
+            if ((uint32_t)i < n && few.d[i].first_group <= g) lo = (uint32_t)i;
+        const Desc d = few.d[lo];
+        return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};
+    });
+}
+
 // rows of ONE packed table picked by an index vector (the embedding lookup, reference ops.py:251-260): output row t = table row
 // indices[t].  The same engine with a different locate -- grid.y walks the output rows (no integer division on the device: its
 // expansion goes through fp32 multiply-adds, which the build's FMA guard rightly refuses), grid.x the groups of one row; the

@@ -46,8 +46,16 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 #ifndef GGQ_GT_SCHED
 #define GGQ_GT_SCHED 0      /* VALU instructions asked for behind every MFMA of a K-step (0 = leave the order to the compiler); A/B builds */
 #endif
+#ifndef GGQ_GT_CROSS
+#define GGQ_GT_CROSS 0x100  /* what may be scheduled ACROSS the line between the two halves of a K-step: LDS reads (so the second half's operands
+                               are already on their way while the first half runs); 0 = nothing; A/B builds */
+#endif
+#ifndef GGQ_GT_DMA
+#define GGQ_GT_DMA 1        /* x tiles and packed spans by LDS-DMA where the second staging buffer fits (0 = through registers everywhere); A/B builds */
+#endif
 #ifndef GGQ_GT_PINGPONG
-#define GGQ_GT_PINGPONG 1   /* the two waves of a SIMD run decode and MFMAs in opposite order (0 = same order); A/B builds */
+#define GGQ_GT_PINGPONG 2   /* the two waves of a SIMD run decode and MFMAs in opposite order: 1 = two halves per K-step, 2 = four sub-phases with the
+                               fragment reads requested first (0 = same order in both waves); A/B builds */
 #endif
 
 GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) & 1u); }
@@ -57,8 +65,18 @@ template <class F> struct GemmGeom {
     static constexpr int UNITS = GT_BN * G::U;                                   // 16-byte units of one staged span
     static constexpr int NUW = (UNITS + GT_THREADS - 1) / GT_THREADS;            // units per thread
     static constexpr int STAGING = NUW * GT_THREADS * 16;                        // LDS bytes (>= 256 * ROW_STRIDE)
-    static constexpr int LDS_BYTES = 4 * GT_TILE + STAGING;
+    // DMA: x tiles and packed spans go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass); the
+    // asynchronous fill needs a SECOND staging buffer, which fits for every format but the two fattest (Q6_K 2 x 56 KiB, Q8_0 2 x 68 KiB):
+    // those keep the register path.
+    static constexpr bool DMA = GGQ_GT_DMA && 4 * GT_TILE + 2 * STAGING <= 160 * 1024;
+    static constexpr int LDS_BYTES = 4 * GT_TILE + (DMA ? 2 : 1) * STAGING;
 };
+
+// one 16-byte piece per lane, global -> LDS without passing through registers; the LDS address is wave-uniform base + 16 * lane
+GGQ_DEV void dma16(const GGQ_GLOBAL uint8_t* src, uint8_t* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const GGQ_GLOBAL void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <class F, int OUT>
 __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
@@ -104,6 +122,18 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
             pf[u] = (ur < (uint32_t)GT_BN && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
         }
     };
+    // the same units by LDS-DMA into staging buffer `buf` (lanes whose unit lies outside the span are masked: those bytes are never read)
+    auto dma_span = [&](uint32_t span, uint32_t buf) {
+#pragma unroll
+        for (int u = 0; u < GG::NUW; u++) {
+            const uint32_t unit = t + (uint32_t)(GT_THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
+            const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
+            const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
+            if (ur < (uint32_t)GT_BN && uu * 16u < a + (uint32_t)G::SPAN_BYTES)
+                dma16(packed + (off - a) + uu * 16u, stg + buf * (uint32_t)GG::STAGING + ((uint32_t)wave * 64u + (uint32_t)(GT_THREADS * u)) * 16u);
+        }
+    };
     auto stage = [&](const u32x4 (&pf)[GG::NUW]) {
 #pragma unroll
         for (int u = 0; u < GG::NUW; u++) *reinterpret_cast<u32x4*>(stg + (t + (uint32_t)(GT_THREADS * u)) * 16u) = pf[u];
@@ -114,12 +144,13 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
     const uint32_t wrow = (n0 + drow < n_rows) ? n0 + drow : n_rows - 1;
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
     const uint32_t dswz = gt_swz(drow);
-    auto decode = [&](uint32_t step, uint8_t* wdst) {
+    auto decode = [&](uint32_t step, uint8_t* wdst, int which = -1) {
         const uint32_t span = step / GT_STEPS, ks = step % GT_STEPS;
         const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
-        const uint8_t* wspan = stg + drow * (uint32_t)G::ROW_STRIDE + a;
+        const uint8_t* wspan = stg + (GG::DMA ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
+            if (which >= 0 && which != s) continue;                                // (compile-time after inlining) one chunk, or both
             const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
             const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, (int)(j % CPB));
             uint32_t w[4];
@@ -142,6 +173,15 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
 #pragma unroll
         for (int i = 0; i < 2; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * GT_PITCH);
     };
+    // ... or by LDS-DMA: the LDS image is lane-linear (row t / 4, piece t % 4), so the XOR swizzle goes on the SOURCE piece
+    auto xdma = [&](uint32_t step, uint8_t* xd) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t row = xrow + 128u * (uint32_t)i;
+            const GGQ_GLOBAL uint8_t* src = xsrc[i] - xpc * 16u + ((xpc ^ gt_swz(row)) * 16u) + (uint64_t)step * GT_PITCH;
+            dma16(src, xd + ((uint32_t)wave * 64u + (uint32_t)(GT_THREADS * i)) * 16u);
+        }
+    };
     auto xstore = [&](const u32x4 (&xr)[2], uint8_t* xd) {
 #pragma unroll
         for (int i = 0; i < 2; i++) *reinterpret_cast<u32x4*>(xd + xdst[i]) = xr[i];
@@ -158,34 +198,55 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[nt][mt][i] = 0.0f;
 
+    // one k-slice of 16: the wave's 2 weight fragments and 4 x fragments (one ds_read_b128 each), then its 8 MFMAs
+    auto frags = [&](const uint8_t* xs, const uint8_t* ws, int kk, u32x4 (&wa)[2], u32x4 (&xb)[4]) {
+        const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + (128u * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
+    };
+    auto mma8 = [&](const u32x4 (&wa)[2], const u32x4 (&xb)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
+    };
     auto mma = [&](const uint8_t* xs, const uint8_t* ws) {
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
-            const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
             u32x4 wa[2], xb[4];
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + (128u * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                for (int mt = 0; mt < 4; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
+            frags(xs, ws, kk, wa, xb);
+            mma8(wa, xb);
         }
     };
 
     // ---- prologue: span 0 staged, tile 0 of both operands in buffer 0
-    u32x4 pf[GG::NUW];
+    u32x4 pf[GG::DMA ? 1 : GG::NUW];
     u32x4 xr[2];
-    fetch(0u, pf);
-    xload(0u, xr);
-    stage(pf);
-    xstore(xr, xt);
-    __syncthreads();
-    if (n_spans > 1) fetch(1u, pf);
-    decode(0u, wt);
-    xload(n_steps > 1 ? 1u : 0u, xr);
-    __syncthreads();
+    auto dma_fence = [&]() {
+        if constexpr (GG::DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every LDS-DMA of this wave has landed; the barrier then publishes it
+        __syncthreads();
+    };
+    if constexpr (GG::DMA) {
+        dma_span(0u, 0u);
+        xdma(0u, xt);
+        dma_fence();
+        if (n_spans > 1) dma_span(1u, 1u);
+        decode(0u, wt);
+        if (n_steps > 1) xdma(1u, xt + GT_TILE);
+        dma_fence();
+    } else {
+        fetch(0u, pf);
+        xload(0u, xr);
+        stage(pf);
+        xstore(xr, xt);
+        __syncthreads();
+        if (n_spans > 1) fetch(1u, pf);
+        decode(0u, wt);
+        xload(n_steps > 1 ? 1u : 0u, xr);
+        __syncthreads();
+    }
 
     // ---- main loop.  One K-step = [decode weight tile t+1 -> W[next]] + [MFMAs on X[cur], W[cur]] + [x registers -> X[next], loads of
     // tile t+2] + one s_barrier.  decode(t + 1) and mma(t) are independent, so a wave may run them in either order: the two waves that
@@ -203,27 +264,66 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
         if (DECODE && (step + 1) % GT_STEPS == 0) {
             // the next K-step opens a new span: every decode of the old one finished before the previous barrier
             const uint32_t span = (step + 1) / GT_STEPS;
-            stage(pf);
-            __syncthreads();
-            if (span + 1 < n_spans) fetch(span + 1, pf);
+            if constexpr (GG::DMA) {
+                // span `span` landed in its buffer steps ago; the OTHER buffer (span - 1) is free: start filling it with span + 1
+                if (span + 1 < n_spans) dma_span(span + 1, (span + 1) & 1u);
+            } else {
+                stage(pf);
+                __syncthreads();
+                if (span + 1 < n_spans) fetch(span + 1, pf);
+            }
+        }
+        if constexpr (GG::DMA) {
+            // x tile of step + 2 ... no: of step + 1, straight into the other x buffer (free since the previous barrier); it has the
+            // whole K-step to land
+            if (step + 1 < n_steps) xdma(step + 1 + 0u, xnxt);
         }
         if constexpr (!DECODE) {
             mma(xcur, wcur);
+        } else if constexpr (GGQ_GT_PINGPONG == 2 && GG::DMA) {     // (the register-staged formats have no room for two fragment sets)
+            // four sub-phases per K-step: the fragments of the first k-slice are requested FIRST (they land while the first decode or
+            // the partner's MFMAs run), then [decode one chunk | 8 MFMAs] twice, the two waves of a SIMD in opposite order
+            u32x4 wa0[2], xb0[4], wa1[2], xb1[4];
+            frags(xcur, wcur, 0, wa0, xb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PONG) {
+                frags(xcur, wcur, 1, wa1, xb1);
+                mma8(wa0, xb0);
+                __builtin_amdgcn_sched_barrier(0);
+                decode(step + 1, wnxt, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma8(wa1, xb1);
+                __builtin_amdgcn_sched_barrier(0);
+                decode(step + 1, wnxt, 1);
+            } else {
+                decode(step + 1, wnxt, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                frags(xcur, wcur, 1, wa1, xb1);
+                mma8(wa0, xb0);
+                __builtin_amdgcn_sched_barrier(0);
+                decode(step + 1, wnxt, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma8(wa1, xb1);
+            }
         } else if constexpr (PONG && GGQ_GT_PINGPONG) {
             mma(xcur, wcur);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(GGQ_GT_CROSS);
             decode(step + 1, wnxt);
         } else {
             decode(step + 1, wnxt);
 #if GGQ_GT_PINGPONG
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(GGQ_GT_CROSS);
 #endif
             mma(xcur, wcur);
         }
-        // x tile of the next step: registers -> LDS; then the loads of the step after (clamped at the end: a harmless re-read)
-        xstore(xr, xnxt);
-        xload(step + 2 < n_steps ? step + 2 : n_steps - 1, xr);
-        __syncthreads();
+        if constexpr (GG::DMA) {
+            dma_fence();
+        } else {
+            // x tile of the next step: registers -> LDS; then the loads of the step after (clamped at the end: a harmless re-read)
+            xstore(xr, xnxt);
+            xload(step + 2 < n_steps ? step + 2 : n_steps - 1, xr);
+            __syncthreads();
+        }
     };
     auto main_loop = [&](auto pong_tag) {
         using T0 = std::integral_constant<int, 0>;

@@ -35,6 +35,11 @@ callers, token_embd / mmproj tables (reference loader.py:253-254,270,386,397) --
 (dequant.dequantize_tensor_via_gpu) instead of running the reference's torch-CPU ops: same bits, CPU result.  Off by default (it
 touches the GPU at load time, before ComfyUI's model management has placed anything).
 
+``lookahead`` (or ``GGQ_LOOKAHEAD=K``): the unpack of the next K - 1 layers is launched together with the one that was asked for -- one
+kernel launch per K layers instead of K (lookahead.DequantAhead; a dependent kernel boundary costs ~1.3 us on MI355X and a single-layer
+launch cannot overlap its reads with its writes).  Same kernels, same bits, fresh tensors; opt-in because up to K - 1 dense weights are
+alive ahead of their use (VRAM the reference's estimate does not see).
+
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
 overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
 and unpacked on a side stream while the current layer's GEMM runs (``overlap="all"``: also for weights already in HBM, where it
@@ -51,7 +56,7 @@ _installed = {}
 
 
 def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
-            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None):
+            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, lookahead=None):
     """Patch the reference modules in place; returns the dict of original functions."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
@@ -62,6 +67,13 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
     hip_dequantize, hip_dequantize_tensor = _hip.dequantize, _hip.dequantize_tensor
     if dense_cache_gb is None and os.environ.get("GGQ_DENSE_CACHE_GB"):
         dense_cache_gb = float(os.environ["GGQ_DENSE_CACHE_GB"])
+    if lookahead is None and os.environ.get("GGQ_LOOKAHEAD"):
+        lookahead = int(os.environ["GGQ_LOOKAHEAD"])
+    ahead = None
+    if lookahead and int(lookahead) > 1:
+        from .lookahead import DequantAhead
+        ahead = DequantAhead(int(lookahead), hip_dequantize_tensor)
+        hip_dequantize_tensor = ahead               # GGQUnsupported from the wrapped function passes straight through
     cache = None
     if dense_cache_gb:
         from .resident import DenseCache
@@ -130,8 +142,28 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         from .overlap import attach
         record, prefetcher = attach(ref_ops.GGMLLayer, resident=(overlap == "all"))
         patched.append(record)
-    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher}
+    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher, "ahead": ahead}
     return orig
+
+
+def scratch_bytes(ref_dequant):
+    """Device memory the opt-ins of this installation hold that the reference's VRAM estimate knows nothing about: the resident dense
+    weights (dense_cache_gb), the side-stream scratch and staging slots (overlap) and the dense weights unpacked ahead of their use
+    (lookahead), in bytes, by option.  INTEGRATION.md section 5 shows where a maintainer adds the total to the ``temp.weight`` reservation
+    of ``ggml_save_to_state_dict`` (reference ops.py:153-158), which is how ComfyUI's model management learns how much VRAM a loaded
+    GGUF model needs beyond its packed bytes."""
+    rec = _installed.get(id(ref_dequant)) or {}
+    out = {"dense_cache": rec["cache"].scratch_bytes() if rec.get("cache") is not None else 0,
+           "overlap": rec["prefetcher"].scratch_bytes() if rec.get("prefetcher") is not None else 0,
+           "lookahead": rec["ahead"].scratch_bytes() if rec.get("ahead") is not None else 0}
+    out["total"] = sum(out.values())
+    return out
+
+
+def lookahead_stats(ref_dequant):
+    """``DequantAhead.stats()`` of an installation (None when ``lookahead`` is off)."""
+    rec = _installed.get(id(ref_dequant))
+    return rec["ahead"].stats() if rec and rec.get("ahead") is not None else None
 
 
 def _gather_embedding(embedding_cls, unsupported):
@@ -205,3 +237,5 @@ def uninstall(ref_dequant):
             rec["cache"].clear()
         if rec.get("prefetcher") is not None:
             rec["prefetcher"].close()
+        if rec.get("ahead") is not None:
+            rec["ahead"].clear()

@@ -114,6 +114,15 @@ typedef struct ggq_desc {
     int32_t reserved;       /* must be 0 */
 } ggq_desc;
 
+/* A FEW tensors, one call, nothing to build or keep: `descs` is HOST memory, read before the call returns; tensors of one
+ * (qtype, compute_dtype, out_dtype) go into ONE kernel launch (their descriptors travel by value in the kernel arguments, up to 8
+ * per launch), in the caller's order.  Same kernels and values as n ggq_dequant calls, minus n - 1 kernel boundaries.
+ * Replaces: the NEXT FEW dequantize_tensor() calls of the per-layer chain (ops.py:177) -- lookahead.py runs the unpack of the
+ * layers it expects next together with the one that was asked for.  n <= GGQ_BATCH_MAX; arguments are checked for every entry
+ * before anything is launched. */
+#define GGQ_BATCH_MAX 32
+int ggq_dequant_batch(const ggq_desc* descs, uint32_t n, void* hip_stream);
+
 typedef struct ggq_plan ggq_plan;
 
 /* Build a launch plan for `n` tensors on the current device: descriptors are grouped by

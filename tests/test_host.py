@@ -534,3 +534,58 @@ def test_bench_median_and_min_helper():
     assert reps == 10 and len(calls) == 13 and 0.001 <= tmin <= med < 0.05          # >= 3 warm-up, >= 10 timed passes, median and min
     med, tmin, reps = bench._median_min(lambda: time.sleep(0.001), budget_s=0.05, min_reps=3, warmup=0)
     assert 20 <= reps <= 200                                                         # ... and as many as the time budget allows
+
+
+def test_lookahead_bookkeeping_on_cpu(pkg, monkeypatch):
+    """lookahead.DequantAhead with a counting stand-in for the batch launch (no GPU): the learnt order, one launch per `depth`
+    layers, results handed out once and only for the very call that was predicted (object, in-place version, dtype, stream), a
+    changed order or a written-to weight recomputed on the spot, dead tensors forgotten."""
+    import gc
+    L = pkg.lookahead
+    T, Q = pkg.ops.GGMLTensor, pkg.qtypes.Q
+    plain, batches = [], []
+
+    def fn(tensor, dtype=None, dequant_dtype=None):
+        plain.append(id(tensor))
+        return torch.full(tuple(getattr(tensor, "tensor_shape", tensor.shape)), float(len(plain)), dtype=dtype)
+
+    def launch(items, stream, index):
+        batches.append([id(t) for t, _ in items])
+        return [torch.full(tuple(t.tensor_shape), -float(len(batches)), dtype=m[0]) for t, m in items]
+
+    ahead = L.DequantAhead(3, fn, launch_batch=launch)
+    # a CPU tensor is "not served here": make the eligibility test say yes without a GPU
+    monkeypatch.setattr(L.DequantAhead, "_mode_of", lambda self, t, dtype, dd: (dtype, dd, 0) if getattr(t, "tensor_type", None) is not None else None)
+    monkeypatch.setattr(L.DequantAhead, "_packed_ok", staticmethod(lambda t: True))
+    monkeypatch.setattr(L._dq, "_raw_stream", lambda index: 7)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    mk = lambda: T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256))
+    ws = [mk() for _ in range(7)]
+    for w in ws:                                                   # pass 1: nothing known, one plain launch per layer
+        ahead(w, torch.float16)
+    assert len(plain) == 7 and not batches
+    outs = [ahead(w, torch.float16) for w in ws]                   # pass 2: the order is known (6 -> 0 from the first call of this pass on)
+    assert batches == [[id(ws[0]), id(ws[1]), id(ws[2])], [id(ws[3]), id(ws[4]), id(ws[5])], [id(ws[6]), id(ws[0]), id(ws[1])]] and len(plain) == 7
+    assert [float(o.flatten()[0]) for o in outs] == [-1, -1, -1, -2, -2, -2, -3]
+    st = ahead.stats()
+    assert st["hits"] == 4 and st["launches"] == 7 + 3 and st["tensors_in_batches"] == 9
+    assert st["held_bytes"] == ahead.scratch_bytes() == 2 * 2 * 256 * 2                  # the last batch ran into the next pass: two weights held
+    del batches[:]
+    outs = [ahead(w, torch.float16) for w in ws]                   # pass 3: 0 and 1 are there already
+    assert batches == [[id(ws[2]), id(ws[3]), id(ws[4])], [id(ws[5]), id(ws[6]), id(ws[0])]] and len(plain) == 7
+    assert ahead.stats()["hits"] == 4 + 5 and ahead.scratch_bytes() == 2 * 256 * 2
+    # what was unpacked ahead is handed out ONCE, and only to the call that was predicted
+    ws[0].add_(1)                                                  # in-place write into the packed bytes: its pending result is stale
+    n_plain, n_b = len(plain), len(batches)
+    ahead(ws[0], torch.float16)
+    assert ahead.stats()["stale_dropped"] == 1 and (len(batches) == n_b + 1 or len(plain) == n_plain + 1)
+    assert float(ahead(ws[1], torch.bfloat16).flatten()[0]) != float(outs[1].flatten()[0]) and ahead.stats()["stale_dropped"] >= 2   # another dtype than predicted
+    # a tensor that is not served (no tensor_type) breaks the chain and goes to the plain function
+    n_plain = len(plain)
+    ahead(torch.zeros(4), torch.float16)
+    assert len(plain) == n_plain + 1 and ahead.stats()["bypassed"] == 1
+    # dead tensors take their entries (and what was unpacked for them) along
+    tracked = ahead.stats()["tracked"]
+    del ws, w, outs
+    gc.collect()
+    assert ahead.stats()["tracked"] == 0 and tracked >= 7 and ahead.scratch_bytes() == 0
