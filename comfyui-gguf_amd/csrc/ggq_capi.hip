@@ -185,14 +185,20 @@ typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 template <class F> struct SoloWhenSmall { static constexpr bool V = false; };
 template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
 
+// Stores of single-tensor launches: non-temporal like the whole-model launches (GGQ_LAYER_NT_STORES = 1, shipped) or plain (0: A/B builds -- does
+// the GEMM that reads the weight next find more of it in L2 / the Infinity Cache?  EXPERIMENTS.md).
+#ifndef GGQ_LAYER_NT_STORES
+#define GGQ_LAYER_NT_STORES 1
+#endif
 template <class T, class F, int ARITH, int OUT>
 hipError_t launch_one(const Desc& d, hipStream_t s)
 {
+    constexpr bool NTS = T::NTS && GGQ_LAYER_NT_STORES;
     const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
+    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
     return hipGetLastError();
 }
 

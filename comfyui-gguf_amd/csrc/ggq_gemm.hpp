@@ -54,7 +54,7 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 #define GGQ_GT_DMA 1        /* x tiles and packed spans by LDS-DMA where the second staging buffer fits (0 = through registers everywhere); A/B builds */
 #endif
 #ifndef GGQ_GT_PINGPONG
-#define GGQ_GT_PINGPONG 2   /* the two waves of a SIMD run decode and MFMAs in opposite order: 1 = two halves per K-step, 2 = four sub-phases with the
+#define GGQ_GT_PINGPONG 1   /* the two waves of a SIMD run decode and MFMAs in opposite order: 1 = two halves per K-step, 2 = four sub-phases with the
                                fragment reads requested first (0 = same order in both waves); A/B builds */
 #endif
 

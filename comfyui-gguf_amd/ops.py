@@ -109,14 +109,14 @@ class GGMLLinear(GGMLLayer):
             from .fused import linear_small
             from .dequant import GGQUnsupported
             try:
-                return linear_small(input, self.weight.to(input.device), self.bias, self.dequant_dtype)
+                return linear_small(input, self.weight, self.bias, self.dequant_dtype, weight_to=input.device)
             except GGQUnsupported:
                 pass
         if self.fuse_mfma_max_m and is_quantized(self.weight) and input.numel() <= self.fuse_mfma_max_m * input.shape[-1]:
             from .fused import linear_mfma
             from .dequant import GGQUnsupported
             try:
-                return linear_mfma(input, self.weight.to(input.device), self.bias, self.dequant_dtype)
+                return linear_mfma(input, self.weight, self.bias, self.dequant_dtype, weight_to=input.device)
             except GGQUnsupported:
                 pass
         if not self.is_ggml_quantized():
