@@ -185,10 +185,13 @@ typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 template <class F> struct SoloWhenSmall { static constexpr bool V = false; };
 template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
 
-// Stores of single-tensor launches: non-temporal like the whole-model launches (GGQ_LAYER_NT_STORES = 1, shipped) or plain (0: A/B builds -- does
-// the GEMM that reads the weight next find more of it in L2 / the Infinity Cache?  EXPERIMENTS.md).
+// Stores of SINGLE-TENSOR launches are PLAIN, not non-temporal.  A whole-weight-set launch streams gigabytes nobody reads back soon: there
+// non-temporal stores are worth +3.4 % (above).  A per-layer launch is the opposite case: the reference's next call is the GEMM that READS the
+// weight just written (ops.py:242-244), and 19-132 MB of plain-stored dense weight are still in L2 / the 256 MiB Infinity Cache when it
+// starts.  Same box, alternating builds, emulated FLUX.1-dev step (304 linears, 4608 tokens, bf16): 73.58 -> 71.15 ms, i.e. the cost of
+// the dequant path per step 4.7 -> 2.4 ms (profiles/r03_flux_forward_emulation_store_policy.json).  GGQ_LAYER_NT_STORES=1 builds the old policy (A/B).
 #ifndef GGQ_LAYER_NT_STORES
-#define GGQ_LAYER_NT_STORES 1
+#define GGQ_LAYER_NT_STORES 0
 #endif
 template <class T, class F, int ARITH, int OUT>
 hipError_t launch_one(const Desc& d, hipStream_t s)
@@ -248,7 +251,8 @@ hipError_t run_few(const Few& few, uint32_t n, uint64_t groups, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, T::NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
+    // (plain stores, like the single-tensor launches: these weights are read by the next few GEMMs)
+    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, T::NTS && GGQ_LAYER_NT_STORES, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
                        xrun_of<T, F>(groups));
     return hipGetLastError();
 }

@@ -139,7 +139,8 @@ class DequantAhead:
             if mode is not None and torch.cuda.is_current_stream_capturing():
                 mode = None
         if mode is None:
-            self._prev = None                                  # the chain is broken here: nothing is predicted across this call
+            # not served here (an F32 bias, a CPU tensor, tracing ...): the plain path, and NO effect on the learnt order -- the reference's
+            # cast_bias_weight asks for the bias right before the weight (ops.py:205-207), which must not cut the chain of weights in two
             self.bypassed += 1
             return self._fn(tensor, dtype, dequant_dtype)
         stream = _dq._raw_stream(mode[2])
