@@ -69,6 +69,7 @@ SYMBOLS = {
     "ggq_abi_version": (_int, []),
     "ggq_build_id": (ctypes.c_char_p, []),
     "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
+    "ggq_dequant_stream": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
     "ggq_dequant_batch": (_int, [ctypes.POINTER(ggq_desc), _u32, _vp]),
     "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),

@@ -173,7 +173,7 @@ template <class T, class F> uint32_t xrun_of(uint64_t groups)      // T = the te
 thread_local int t_last_hip = 0;
 constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 
-typedef hipError_t (*one_fn)(const Desc&, hipStream_t);
+typedef hipError_t (*one_fn)(const Desc&, hipStream_t, bool);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
 typedef hipError_t (*rows_fn)(const void*, const int64_t*, void*, uint64_t, uint32_t, uint64_t, hipStream_t);
 typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
@@ -185,48 +185,54 @@ typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 template <class F> struct SoloWhenSmall { static constexpr bool V = false; };
 template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
 
-// Stores of SINGLE-TENSOR launches are PLAIN, not non-temporal.  A whole-weight-set launch streams gigabytes nobody reads back soon: there
-// non-temporal stores are worth +3.4 % (above).  A per-layer launch is the opposite case: the reference's next call is the GEMM that READS the
-// weight just written (ops.py:242-244), and 19-132 MB of plain-stored dense weight are still in L2 / the 256 MiB Infinity Cache when it
-// starts.  Same box, alternating builds, emulated FLUX.1-dev step (304 linears, 4608 tokens, bf16): 73.58 -> 71.15 ms, i.e. the cost of
-// the dequant path per step 4.7 -> 2.4 ms (profiles/r03_flux_forward_emulation_store_policy.json).  GGQ_LAYER_NT_STORES=1 builds the old policy (A/B).
-#ifndef GGQ_LAYER_NT_STORES
-#define GGQ_LAYER_NT_STORES 0
-#endif
-template <class T, class F, int ARITH, int OUT>
-hipError_t launch_one(const Desc& d, hipStream_t s)
+// Stores of SINGLE-TENSOR launches are PLAIN by default, not non-temporal.  A whole-weight-set launch streams gigabytes nobody reads back
+// soon: there non-temporal stores are worth +3.4 % (above).  A per-layer launch is the opposite case: the reference's next call is the GEMM
+// that READS the weight just written (ops.py:242-244), and 19-132 MB of plain-stored dense weight are still in L2 / the 256 MiB Infinity
+// Cache when it starts.  Same box, alternating builds, emulated FLUX.1-dev step (304 linears, 4608 tokens, bf16): 73.58 -> 71.15 ms, i.e.
+// the cost of the dequant path per step 4.7 -> 2.4 ms (profiles/r03_flux_forward_emulation_store_policy.json) -- although the SAME kernels,
+// launched back to back with no consumer in between, are 8-38 % SLOWER with plain stores (3072x3072 Q4_K -> bf16: 7.1 vs 5.1 us;
+// profiles/r03_layer_latency_store_policy.json).  Both instantiations ship: ggq_dequant stores plain (its caller is a layer), ggq_dequant_stream
+// stores non-temporal (for results nobody reads back soon).  GGQ_LAYER_NT_STORES=1 (environment) makes ggq_dequant stream too (A/B runs).
+bool layer_nt_default()
 {
-    constexpr bool NTS = T::NTS && GGQ_LAYER_NT_STORES;
+    static const int o = env_int("GGQ_LAYER_NT_STORES", 0, 1);
+    return o == 1;
+}
+
+template <class T, class F, int ARITH, int OUT>
+hipError_t launch_one(const Desc& d, hipStream_t s, bool nt)
+{
     const uint64_t groups = (d.n_blocks + T::G - 1) / T::G;
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, NTS, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
+    if (nt && T::NTS) hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, true, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
+    else hipLaunchKernelGGL((dequant_one<F, T::G, OUT, T::NTL, false, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, d, groups, xrun_of<T, F>(groups));
     return hipGetLastError();
 }
 
 template <class F, int ARITH, int OUT>
-hipError_t run_one(const Desc& d, hipStream_t s)
+hipError_t run_one(const Desc& d, hipStream_t s, bool nt)
 {
     using Big = TuneFor<F, ARITH, OUT>;                              // the shape of whole-model launches
     using Fp16Out = TuneFor<F, ARITH, OUT_F16>;
     const uint64_t elements = d.n_blocks * (uint64_t)F::BS;
     if constexpr (MidShape<F>::V && OUT != OUT_F32) {                // (fp32 output already stores twice the rows per wave)
-        if (elements > MID_MIN_ELEMENTS && elements < MID_MAX_ELEMENTS) return launch_one<TuneMid<F>, F, ARITH, OUT>(d, s);
+        if (elements > MID_MIN_ELEMENTS && elements < MID_MAX_ELEMENTS) return launch_one<TuneMid<F>, F, ARITH, OUT>(d, s, nt);
     }
     const bool layer_sized = elements < XRUN_MIN_ELEMENTS;
     if constexpr (SoloWhenSmall<F>::V && Big::COOP) {
-        if (layer_sized) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s);
+        if (layer_sized) return launch_one<TuneSolo<F>, F, ARITH, OUT>(d, s, nt);
     }
     // one-wave teams chosen for the output cast only (CoopForOut): a whole-model effect too.  At layer size, bf16 output, rocprof
     // kernel times coop vs solo: 3072x3072 Q4_K 6.09 vs 6.52 us, Q5_K 6.21 vs 6.76, IQ4_XS 6.19 vs 6.80; 3072x12288 Q5_K 18.1 vs 18.9,
     // IQ4_XS 17.1 vs 17.9, Q4_K level (profiles/r01_layer_kernel_times_bf16_out_coop_vs_solo.json): single layers stay coop
 #ifndef GGQ_CAST_SOLO_AT_LAYER_SIZE      /* A/B builds define it */
     if constexpr (!Big::COOP && Fp16Out::COOP) {
-        if (layer_sized) return launch_one<Fp16Out, F, ARITH, OUT>(d, s);
+        if (layer_sized) return launch_one<Fp16Out, F, ARITH, OUT>(d, s, nt);
     }
 #endif
-    return launch_one<Big, F, ARITH, OUT>(d, s);
+    return launch_one<Big, F, ARITH, OUT>(d, s, nt);
 }
 
 // The coarse index replaces the binary search only for the COOP teams: bench.py, alternating builds on one box, measured
@@ -252,7 +258,7 @@ hipError_t run_few(const Few& few, uint32_t n, uint64_t groups, hipStream_t s)
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
     // (plain stores, like the single-tensor launches: these weights are read by the next few GEMMs)
-    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, T::NTS && GGQ_LAYER_NT_STORES, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
+    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, false, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
                        xrun_of<T, F>(groups));
     return hipGetLastError();
 }
@@ -392,7 +398,17 @@ int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int
     const int rc = check_tensor(f, packed, out, n_blocks, compute_dtype, out_dtype);
     if (rc != GGQ_OK || n_blocks == 0) return rc;
     const Desc d{static_cast<const uint8_t*>(packed), static_cast<uint8_t*>(out), n_blocks, 0};
-    const hipError_t e = f->one[compute_dtype][out_dtype](d, static_cast<hipStream_t>(hip_stream));
+    const hipError_t e = f->one[compute_dtype][out_dtype](d, static_cast<hipStream_t>(hip_stream), layer_nt_default());
+    return e == hipSuccess ? GGQ_OK : hip_fail(e);
+}
+
+int ggq_dequant_stream(int qtype, const void* packed, uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* hip_stream)
+{
+    const FormatEntry* f = find_format(qtype);
+    const int rc = check_tensor(f, packed, out, n_blocks, compute_dtype, out_dtype);
+    if (rc != GGQ_OK || n_blocks == 0) return rc;
+    const Desc d{static_cast<const uint8_t*>(packed), static_cast<uint8_t*>(out), n_blocks, 0};
+    const hipError_t e = f->one[compute_dtype][out_dtype](d, static_cast<hipStream_t>(hip_stream), true);
     return e == hipSuccess ? GGQ_OK : hip_fail(e);
 }
 

@@ -140,7 +140,13 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     // workgroup into LDS; needs rows % 8 == 0); 0 = pick from m: one 32-row block up to m = 32, 64-row tiles to m < GGQ_TILE_MIN_M, the
     // shared-tile kernel from there on (profiles/r03_gemm_tile_bench.json).
     int shape;
-    if (tile_rows == 0) shape = m <= 32 ? 0 : ((m < tile_min_m() || rows % 8u != 0) ? (m < 384 ? 1 : 2) : 3);
+    if (tile_rows == 0) {
+        // the shared-tile kernel needs enough 256 x 256 tiles to fill the chip (one workgroup per CU, 256 CUs): with fewer than half as many
+        // tiles as CUs the K-split kernel's 32-column workgroups win (emulated FLUX step at 512 / 1024 tokens, profiles/r03_flux_forward_emulation_fused.json)
+        const uint32_t n_tiles = ((m + GT_BM - 1) / GT_BM) * ((rows + GT_BN - 1) / GT_BN);
+        const bool tile_ok = m >= tile_min_m() && rows % 8u == 0 && n_tiles >= 128u;
+        shape = m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2));
+    }
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
     if (shape == 3 && rows % 8u != 0) return GGQ_ERR_ARG;

@@ -268,6 +268,21 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
     return _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype)
 
 
+def dequantize_tensor_streaming(tensor, dtype=None, dequant_dtype=None):
+    """``dequantize_tensor`` for a result that is NOT read back soon (a tensor unpacked at load time, a measurement of the unpack
+    alone): same kernels and values, non-temporal stores (include/ggq.h ``ggq_dequant_stream``).  The per-layer path stores plain,
+    because the layer's GEMM reads the weight next and finds it in cache.  Not for concurrent use with dequantize_tensor from another
+    thread (it swaps the module's launch binding for the duration of the call)."""
+    global _ggq_dequant
+    if _ggq_dequant is None:
+        _bind()
+    keep, _ggq_dequant = _ggq_dequant, _native.lib().ggq_dequant_stream
+    try:
+        return dequantize_tensor(tensor, dtype, dequant_dtype)
+    finally:
+        _ggq_dequant = keep
+
+
 def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype):
     """dequant.py:15-28 for everything the hot path above does not take: passthrough types, plain-int qtypes, result dtypes the
     kernels do not emit, carriers that are not tensors, BF16, tracing under torch.compile, unknown qtypes."""
@@ -317,7 +332,7 @@ def dequantize_tensor_via_gpu(tensor, dtype=None, dequant_dtype=None, device=Non
         data = _as_bytes(tensor, align=False).to(device, non_blocking=False)
     from .ops import GGMLTensor
     carrier = GGMLTensor(data, tensor_type=key, tensor_shape=oshape if oshape is not None else tensor.shape)
-    return dequantize_tensor(carrier, dtype, dequant_dtype).cpu()
+    return dequantize_tensor_streaming(carrier, dtype, dequant_dtype).cpu()        # read back over PCIe, not by a kernel: stream the stores
 
 
 import os as _os

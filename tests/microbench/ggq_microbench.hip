@@ -830,6 +830,24 @@ static void ab_occ1_all()
     ab_occ1<ggq::FmtQ6_K, 8, false>("Q6_K", 9, 6);
 }
 
+// Round 3 (Next #5): Q3_K reads 1.127x its packed bytes because neighbouring 880-byte groups share a 128-byte line that two
+// XCDs then both fetch.  A group of 64 super-blocks is 7040 bytes = 55 lines EXACTLY: no shared line under any mapping.  Does that shape win?
+static void ab_q3k_line_exact()
+{
+    using F = ggq::FmtQ3_K;
+    Pool P = make_pool(QTS[6], 64);
+    AB ab;
+    ab_add<F, 8, false, true, 1, 0, false, -1, 1, false>(ab, "Q3_K", P);                 // shipped: one-wave teams, identity mapping
+    ab_add<F, 64, false, true, 4, 0, false, -1, 1, true>(ab, "Q3_K", P);                 // 4 waves share 64 super-blocks (16 store rows per wave)
+    ab_add<F, 64, false, true, 4, 0, false, -1, 1, true>(ab, "Q3_K", P, 0, 3);           // ... XCD runs of 8 groups
+    ab_add<F, 64, false, true, 8, 0, false, -1, 1, true>(ab, "Q3_K", P);                 // 8 waves share them (8 rows per wave)
+    ab_add<F, 64, false, true, 16, 0, false, -1, 1, true>(ab, "Q3_K", P);                // 16 waves (4 rows per wave)
+    ab_add<F, 64, false, true, 16, 0, false, -1, 1, true>(ab, "Q3_K", P, 0, 3);
+    ab_add<F, 32, false, true, 4, 0, false, -1, 1, true>(ab, "Q3_K", P, 0, 4);           // round 1's best workgroup-team shape, for reference
+    ab.run(12, 4);
+    free_pool(P);
+}
+
 static void ab_small_all()      // profiles/r01_microbench_p_q2k_q3k_shapes.txt
 {
     ab_small_groups<ggq::FmtQ2_K, false>("Q2_K", 5);
@@ -1215,6 +1233,11 @@ int main(int argc, char** argv)
         ab_layer<ggq::FmtQ6_K, 8>("Q6_K", 9, {3072ull * 3072, 4096ull * 4096, 9216ull * 3072});
         ab_layer<ggq::FmtQ2_K, 8>("Q2_K", 5, {3072ull * 3072, 4096ull * 4096});
         ab_layer<ggq::FmtIQ4_XS, 8>("IQ4_XS", 11, {3072ull * 3072, 4096ull * 4096});
+    }
+    if (what == "abq3k") ab_q3k_line_exact();
+    if (what == "ablds") {          // round 3: LDS-staged vs no-LDS ("direct", zero bank conflicts by construction) for the 2-byte-aligned legacy formats
+        ab_big<ggq::FmtQ4_0, 64>("Q4_0", 0, 64);
+        ab_big<ggq::FmtQ8_0, 64>("Q8_0", 4, 64);
     }
     if (what == "ab") ab_all();
     if (what == "abxcd") ab_xcd_all();

@@ -281,6 +281,21 @@ def test_property_scale_linearity_full_size(pkg, name):
     assert torch.equal(pkg.dequant.dequantize(torch.from_numpy(blocks.reshape(-1)).to(DEV), q, (n * bs,)), a)   # deterministic
 
 
+def test_streaming_store_entry_point_gives_the_same_bits(pkg):
+    """ggq_dequant stores plain (its caller is a layer whose GEMM reads the weight next), ggq_dequant_stream non-temporal (results
+    nobody reads back soon); dequantize_tensor_streaming is the host name of the latter.  Same kernels otherwise: same bits, every
+    team shape (a small tensor, a layer-sized one, one beyond the layer-sized range), fp16 and bf16 results."""
+    Q = pkg.qtypes.Q
+    for q, shape in ((Q.Q4_K, (24, 512)), (Q.Q8_0, (3072, 3072)), (Q.Q5_K, (3072, 12288)), (Q.Q3_K, (4096, 4096))):
+        n_blocks = pkg.synth.n_blocks_for(q, shape[0] * shape[1])
+        t = pkg.ops.GGMLTensor(pkg.synth.device_blocks(q, n_blocks, DEV, 5, mode="signed"), tensor_type=q, tensor_shape=shape)
+        for dt in (torch.float16, torch.bfloat16):
+            a = pkg.dequant.dequantize_tensor(t, dt)
+            b = pkg.dequant.dequantize_tensor_streaming(t, dt)
+            assert a.dtype == b.dtype == dt and torch.equal(a.view(torch.int16), b.view(torch.int16)), (q, shape, dt)
+    assert pkg.dequant._ggq_dequant is not pkg._native.lib().ggq_dequant_stream          # the binding was put back
+
+
 def test_non_default_stream_ordering(pkg):
     """The launch goes to torch's CURRENT stream: producer copy and consumer read on a side stream."""
     q = pkg.qtypes.Q.Q4_K
