@@ -2,6 +2,7 @@
 #include "ggq_linear.hpp"
 #include "ggq_mfma.hpp"
 #include "ggq_gemm.hpp"
+#include "ggq_gemm64.hpp"
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
 
@@ -101,9 +102,45 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
+// ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp) for the formats that define it; GGQ_TILE64=0 (environment, read once:
+// A/B runs) keeps the generic K-step-32 kernel for them too
+bool tile64_enabled()
+{
+    static const bool v = [] {
+        const char* e = getenv("GGQ_TILE64");
+        return !(e && *e == '0');
+    }();
+    return v;
+}
+
+template <class F, int OUT>
+hipError_t launch_tile_any(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    if constexpr (Step64<F>::OK) {
+        if (tile64_enabled()) {
+            constexpr uint32_t lds = (uint32_t)Gemm64Geom<F>::LDS_BYTES;
+            static_assert(lds <= 160 * 1024, "one workgroup's LDS");
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            static std::atomic<uint64_t> raised{0};
+            const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
+            if (!(raised.load(std::memory_order_relaxed) & bit)) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile64<F, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                raised.fetch_or(bit, std::memory_order_relaxed);
+            }
+            const uint32_t tiles_m = (m + GT_BM - 1) / GT_BM, tiles_n = (rows + GT_BN - 1) / GT_BN;
+            hipLaunchKernelGGL((linear_tile64<F, OUT>), dim3(tiles_m * tiles_n), dim3(GT_THREADS), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
+                               static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, tiles_m, tiles_n);
+            return hipGetLastError();
+        }
+    }
+    return launch_tile<F, OUT>(packed, x, bias, y, m, rows, cols, s);
+}
+
 constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4 (K-split kernel), then the 256 x 256 shared-tile kernel
 struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][shape]
-#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>}
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile_any<F, OUT>}
 #define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),

@@ -332,7 +332,7 @@ def dequantize_tensor_via_gpu(tensor, dtype=None, dequant_dtype=None, device=Non
         data = _as_bytes(tensor, align=False).to(device, non_blocking=False)
     from .ops import GGMLTensor
     carrier = GGMLTensor(data, tensor_type=key, tensor_shape=oshape if oshape is not None else tensor.shape)
-    return dequantize_tensor_streaming(carrier, dtype, dequant_dtype).cpu()        # read back over PCIe, not by a kernel: stream the stores
+    return dequantize_tensor(carrier, dtype, dequant_dtype).cpu()
 
 
 import os as _os
