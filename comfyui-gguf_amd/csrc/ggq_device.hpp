@@ -488,11 +488,24 @@ template <> struct OutBytes<OUT_F32> { static constexpr int V = 4; };
 typedef GGQ_GLOBAL const uint8_t* gcptr;
 typedef GGQ_GLOBAL uint8_t* gptr;
 
+// GGQ_PLAIN_STORE_POLICY (A/B builds only): the cache-policy bits of the stores that are NOT non-temporal -- the single-tensor launches, whose
+// output the next kernel reads (ggq_capi.hip).  0 = plain (shipped), 2 = sc1, 3 = sc0 sc1, 6 = sc0 (gfx950 store policies; EXPERIMENTS.md A9).
+#ifndef GGQ_PLAIN_STORE_POLICY
+#define GGQ_PLAIN_STORE_POLICY 0
+#endif
 template <bool NT, class T>
 GGQ_DEV void gstore(gptr p, T v)
 {
-    if constexpr (NT) __builtin_nontemporal_store(v, (GGQ_GLOBAL T*)p);
-    else *(GGQ_GLOBAL T*)p = v;
+    if constexpr (NT) {
+        __builtin_nontemporal_store(v, (GGQ_GLOBAL T*)p);
+    } else if constexpr (GGQ_PLAIN_STORE_POLICY == 0 || sizeof(T) != 16) {
+        *(GGQ_GLOBAL T*)p = v;
+    } else {
+        const u32x4 u = __builtin_bit_cast(u32x4, v);
+        if constexpr (GGQ_PLAIN_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(u) : "memory");
+        else if constexpr (GGQ_PLAIN_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(u) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(u) : "memory");
+    }
 }
 
 template <bool NT>

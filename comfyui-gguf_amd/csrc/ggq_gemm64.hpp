@@ -1,5 +1,8 @@
-// ggq_gemm64.hpp -- the shared-tile fused GEMM of ggq_gemm.hpp with K-steps of 64 instead of 32, for the formats whose packed bytes
-// can be staged PER K-STEP (Step64<F>): half as many barriers, LDS latency exposures and fragment-read restarts per MFMA.
+// ggq_gemm64.hpp -- EXPERIMENT (compiled only with -DGGQ_WITH_TILE64; EXPERIMENTS.md A2b): the shared-tile fused GEMM of ggq_gemm.hpp with
+// K-steps of 64 instead of 32, for the formats whose packed bytes can be staged PER K-STEP (Step64<F>): half as many barriers, LDS latency
+// exposures and fragment-read restarts per MFMA.  Bit-identical weights, passes the same tests -- and measured 13 % SLOWER (Q4_K 12288x3072,
+// 4608 rows: 465 vs 410 us; one tile alone 109 vs 94 us): with 32 MFMAs and a 222-instruction decode per wave between barriers, each wave's own
+// serial chain (decode, then four fragment-read / 8-MFMA rounds) is what the step takes, and only two waves per SIMD are there to overlap it.
 //
 // Why it needs its own staging.  ggq_gemm.hpp decodes through the dequant kernels' generic `fields(block, chunk)`, which wants a whole
 // 256-element super-block of every row in LDS: 36 KiB for Q4_K next to 4 x 16 KiB of operand tiles.  With K-steps of 64 the operand tiles

@@ -2,7 +2,9 @@
 #include "ggq_linear.hpp"
 #include "ggq_mfma.hpp"
 #include "ggq_gemm.hpp"
+#ifdef GGQ_WITH_TILE64       /* A/B builds only: the K-step-64 variant measured 13 % slower (EXPERIMENTS.md A2b) */
 #include "ggq_gemm64.hpp"
+#endif
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
 
@@ -102,22 +104,15 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
-// ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp) for the formats that define it; GGQ_TILE64=0 (environment, read once:
-// A/B runs) keeps the generic K-step-32 kernel for them too
-bool tile64_enabled()
-{
-    static const bool v = [] {
-        const char* e = getenv("GGQ_TILE64");
-        return !(e && *e == '0');
-    }();
-    return v;
-}
-
+// ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp): built, correct, 13 % SLOWER than the K-step-32 kernel (EXPERIMENTS.md
+// A2b), so it is compiled only into A/B builds (-DGGQ_WITH_TILE64; GGQ_TILE64=0 in the environment then switches it off again)
 template <class F, int OUT>
 hipError_t launch_tile_any(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
+#ifdef GGQ_WITH_TILE64
     if constexpr (Step64<F>::OK) {
-        if (tile64_enabled()) {
+        static const bool enabled = [] { const char* e = getenv("GGQ_TILE64"); return !(e && *e == '0'); }();
+        if (enabled) {
             constexpr uint32_t lds = (uint32_t)Gemm64Geom<F>::LDS_BYTES;
             static_assert(lds <= 160 * 1024, "one workgroup's LDS");
             int dev = 0;
@@ -135,6 +130,7 @@ hipError_t launch_tile_any(const void* packed, const void* x, const void* bias, 
             return hipGetLastError();
         }
     }
+#endif
     return launch_tile<F, OUT>(packed, x, bias, y, m, rows, cols, s);
 }
 
