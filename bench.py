@@ -406,12 +406,12 @@ def run_per_layer(pkg, args, device, fence):
     the 304 tensors of the FLUX.1-dev set in model order, bf16 result (FLUX computes in bf16) -- 304 launches per pass instead of
     the 2 of the whole-set plan.  Three views, because they answer different questions:
       * `value` = STANDALONE, GPU-bound: the 304 launches replayed back to back from a captured HIP graph, nothing reading the results --
-        with the shipped store policy of the per-layer entry point (plain stores) and, beside it, with non-temporal stores
+        with the shipped store policy of the per-layer entry point (write-through, sc1) and, beside it, with non-temporal stores
         (ggq_dequant_stream), which are faster here precisely because nobody reads the weight back;
       * `eager` = the python loop as ComfyUI runs it (host enqueue cost included; outputs go back to torch's allocator after every call);
       * `in_context` = what the path costs where it actually runs: every layer's unpack followed by its F.linear on 4608 tokens (the
-        reference's forward, ops.py:242-244), against the same GEMMs on dense weights kept resident -- there the PLAIN stores win by a wide
-        margin, because the GEMM finds the weight in L2 / the Infinity Cache; that is why they ship.
+        reference's forward, ops.py:242-244), against the same GEMMs on dense weights kept resident -- there the shipped write-through
+        stores win by a wide margin over non-temporal ones, because the GEMM finds the weight in the Infinity Cache; that is why they ship.
     Three timed regions each, median reported, HIP events on the launch stream."""
     manifest = pkg.manifests.flux_dev(args.mix)
     tensors = []
@@ -462,7 +462,7 @@ def run_per_layer(pkg, args, device, fence):
 
     from oracle import plan_check
     standalone, parity = {}, None
-    for policy, fn in (("plain", dq), ("streaming", dq_stream)):
+    for policy, fn in (("shipped_sc1", dq), ("streaming_nt", dq_stream)):
         side = torch.cuda.Stream(device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
@@ -505,19 +505,19 @@ def run_per_layer(pkg, args, device, fence):
 
     (d_ms, _), d_regs = median(step_dense, 3)
     ctx = {"tokens": tokens, "ms_per_step_dense_resident": round(d_ms, 3), "dense_regions_ms": d_regs}
-    for policy, fn in (("plain", dq), ("streaming", dq_stream)):
+    for policy, fn in (("shipped_sc1", dq), ("streaming_nt", dq_stream)):
         (q_ms, _), regs = median(step_with(fn), 3)
         ctx[policy] = {"ms_per_step": round(q_ms, 3), "dequant_cost_ms_per_step": round(q_ms - d_ms, 3), "regions_ms": regs}
     del dense
     torch.cuda.empty_cache()
 
-    g = standalone["plain"]
+    g = standalone["shipped_sc1"]
     return {
         "metric": "dequant GB/s, one dequantize_tensor() launch per layer (packed in -> bf16 out), (in+out) bytes / time",
         "value": g["GBps"], "unit": "GB/s", "ms_per_step": g["ms_per_pass"],
         "config": {"workload": f"FLUX.1-dev weight set ({len(manifest)} tensors, {args.mix}) through the per-layer entry point, one launch per tensor in model "
                                "order, bf16 result; value = standalone GPU-bound (the launches replayed from a captured HIP graph, nothing reads the results) with the "
-                               "shipped store policy (plain stores: chosen for the in-context cost, see in_context)",
+                               "shipped store policy (write-through sc1 stores: chosen for the in-context cost, see in_context)",
                    "launches_per_pass": len(manifest), "passes_per_region": passes, "bytes_per_pass": nbytes,
                    "standalone_gpu_bound": standalone,
                    "eager_regions_ms": eager_regions, "eager_ms_per_pass": round(e_ms, 5), "eager_GBps": round(nbytes / (e_ms * 1e-3) / 1e9, 1),
@@ -528,9 +528,9 @@ def run_per_layer(pkg, args, device, fence):
                    "in_context": ctx,
                    "parity_vs_oracle": parity},
         "roofline": {"bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "ggq::dequant_one<Fmt*, ...> (one launch per tensor; team shape picked per tensor size; plain stores)",
+                     "traffic": None, "kernel": "ggq::dequant_one<Fmt*, ...> (one launch per tensor; team shape picked per tensor size; sc1 stores)",
                      "algorithmic_bytes_per_launch": nbytes // len(manifest), "avg_launch_ms": round(g["ms_per_pass"] / len(manifest), 6),
-                     "with_streaming_stores": {"achieved": standalone["streaming"]["GBps"], "frac": round(standalone["streaming"]["GBps"] / HBM_PEAK_GBS, 4)}},
+                     "with_streaming_stores": {"achieved": standalone["streaming_nt"]["GBps"], "frac": round(standalone["streaming_nt"]["GBps"] / HBM_PEAK_GBS, 4)}},
         "cpu_baseline": None,
     }
 

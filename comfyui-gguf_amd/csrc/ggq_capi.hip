@@ -185,14 +185,14 @@ typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 template <class F> struct SoloWhenSmall { static constexpr bool V = false; };
 template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
 
-// Stores of SINGLE-TENSOR launches are PLAIN by default, not non-temporal.  A whole-weight-set launch streams gigabytes nobody reads back
+// Stores of SINGLE-TENSOR launches are WRITE-THROUGH (sc1), not non-temporal.  A whole-weight-set launch streams gigabytes nobody reads back
 // soon: there non-temporal stores are worth +3.4 % (above).  A per-layer launch is the opposite case: the reference's next call is the GEMM
-// that READS the weight just written (ops.py:242-244), and 19-132 MB of plain-stored dense weight are still in L2 / the 256 MiB Infinity
-// Cache when it starts.  Same box, alternating builds, emulated FLUX.1-dev step (304 linears, 4608 tokens, bf16): 73.58 -> 71.15 ms, i.e.
-// the cost of the dequant path per step 4.7 -> 2.4 ms (profiles/r03_flux_forward_emulation_store_policy.json) -- although the SAME kernels,
-// launched back to back with no consumer in between, are 8-38 % SLOWER with plain stores (3072x3072 Q4_K -> bf16: 7.1 vs 5.1 us;
-// profiles/r03_layer_latency_store_policy.json).  Both instantiations ship: ggq_dequant stores plain (its caller is a layer), ggq_dequant_stream
-// stores non-temporal (for results nobody reads back soon).  GGQ_LAYER_NT_STORES=1 (environment) makes ggq_dequant stream too (A/B runs).
+// that READS the weight just written (ops.py:242-244), and 19-132 MB of dense weight that were not stored non-temporally are still in the
+// 256 MiB Infinity Cache when it starts.  Emulated FLUX.1-dev step (304 linears, 4608 tokens, bf16), same box, alternating: cost of the dequant
+// path per step 5.0 ms with non-temporal stores, 2.2 ms with plain stores, 1.7-2.0 ms with sc1 -- and standalone (nothing reads the result) the sc1
+// launch is within 3 % of the non-temporal one where the plain one is 8-38 % slower (3072x3072 Q4_K -> bf16: 5.25 / 5.1 / 7.15 us;
+// profiles/r03_layer_store_cache_policy.json, r03_flux_forward_emulation_store_policy.json).  Both instantiations ship: ggq_dequant stores sc1 (its caller
+// is a layer), ggq_dequant_stream non-temporal (results nobody reads back soon).  GGQ_LAYER_NT_STORES=1 (environment) makes ggq_dequant stream too (A/B).
 bool layer_nt_default()
 {
     static const int o = env_int("GGQ_LAYER_NT_STORES", 0, 1);
@@ -257,7 +257,7 @@ hipError_t run_few(const Few& few, uint32_t n, uint64_t groups, hipStream_t s)
     if (groups == 0) return hipSuccess;
     const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
     if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    // (plain stores, like the single-tensor launches: these weights are read by the next few GEMMs)
+    // (sc1 stores, like the single-tensor launches: these weights are read by the next few GEMMs)
     hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, false, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
                        xrun_of<T, F>(groups));
     return hipGetLastError();

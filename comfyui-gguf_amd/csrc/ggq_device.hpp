@@ -488,10 +488,14 @@ template <> struct OutBytes<OUT_F32> { static constexpr int V = 4; };
 typedef GGQ_GLOBAL const uint8_t* gcptr;
 typedef GGQ_GLOBAL uint8_t* gptr;
 
-// GGQ_PLAIN_STORE_POLICY (A/B builds only): the cache-policy bits of the stores that are NOT non-temporal -- the single-tensor launches, whose
-// output the next kernel reads (ggq_capi.hip).  0 = plain (shipped), 2 = sc1, 3 = sc0 sc1, 6 = sc0 (gfx950 store policies; EXPERIMENTS.md A9).
+// The stores that are NOT non-temporal -- the single-tensor launches, whose output the next kernel reads (ggq_capi.hip) -- carry the sc1 cache
+// policy: written through to memory and dropped from the XCD's L2, yet still found in the Infinity Cache by the GEMM that reads the weight next.
+// Measured against plain, sc0, sc0 sc1 and non-temporal stores on one box (profiles/r03_layer_store_cache_policy.json): standalone 3072x3072 Q4_K ->
+// bf16 5.25 us (nt 5.1, plain 7.15), cost of the dequant path per emulated FLUX step 1.7-2.0 ms (plain 2.2, nt 5.0).  GGQ_PLAIN_STORE_POLICY
+// (A/B builds): 0 = plain, 2 = sc1 (shipped), 3 = sc0 sc1, 6 = sc0.  hipcc has no builtin for a 16-byte sc1 store, hence the asm statement; it is
+// the last thing a team does before its waves retire, so no later access depends on the compiler counting it.
 #ifndef GGQ_PLAIN_STORE_POLICY
-#define GGQ_PLAIN_STORE_POLICY 0
+#define GGQ_PLAIN_STORE_POLICY 2
 #endif
 template <bool NT, class T>
 GGQ_DEV void gstore(gptr p, T v)

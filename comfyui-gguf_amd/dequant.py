@@ -270,7 +270,7 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
 
 def dequantize_tensor_streaming(tensor, dtype=None, dequant_dtype=None):
     """``dequantize_tensor`` for a result that is NOT read back soon (a tensor unpacked at load time, a measurement of the unpack
-    alone): same kernels and values, non-temporal stores (include/ggq.h ``ggq_dequant_stream``).  The per-layer path stores plain,
+    alone): same kernels and values, non-temporal stores (include/ggq.h ``ggq_dequant_stream``).  The per-layer path stores write-through (sc1),
     because the layer's GEMM reads the weight next and finds it in cache.  Not for concurrent use with dequantize_tensor from another
     thread (it swaps the module's launch binding for the duration of the call)."""
     global _ggq_dequant

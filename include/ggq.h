@@ -86,10 +86,10 @@ const char* ggq_build_id(void);
  * n_blocks == 0 is a no-op that returns GGQ_OK. */
 int ggq_dequant(int qtype, const void* packed, uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* hip_stream);
 
-/* The same kernels with NON-TEMPORAL stores.  ggq_dequant stores plain: its caller is a layer whose very next kernel reads the
- * weight (ops.py:242-244), and a plain-stored weight is still in L2 / the Infinity Cache then (the emulated FLUX.1-dev step is 2.4 ms
- * faster for it).  For a result nobody reads back soon -- a tensor dequantized at load time, a benchmark of the unpack alone --
- * non-temporal stores are 8-38 % faster.  Same arguments, same values. */
+/* The same kernels with NON-TEMPORAL stores.  ggq_dequant stores write-through (sc1): its caller is a layer whose very next kernel reads
+ * the weight (ops.py:242-244) and then finds it in the Infinity Cache (the emulated FLUX.1-dev step is 3 ms faster for it).  For a
+ * result nobody reads back soon -- a tensor dequantized at load time, a benchmark of the unpack alone -- non-temporal stores are a
+ * few per cent faster.  Same arguments, same values. */
 int ggq_dequant_stream(int qtype, const void* packed, uint64_t n_blocks, void* out, int compute_dtype, int out_dtype, void* hip_stream);
 
 /* Same with compute_dtype = out_dtype = GGQ_F16 (the stock node: dequantize(data, qtype, oshape)). */
