@@ -506,9 +506,11 @@ GGQ_DEV void gstore(gptr p, T v)
         *(GGQ_GLOBAL T*)p = v;
     } else {
         const u32x4 u = __builtin_bit_cast(u32x4, v);
-        if constexpr (GGQ_PLAIN_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(u) : "memory");
-        else if constexpr (GGQ_PLAIN_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(u) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(u) : "memory");
+        // (the s_nop 1 INSIDE the statement: hipcc does not model an asm store, and its next instruction could overwrite the data registers
+        // before the store has read them -- cdna_hip_programming.md section 5.7 item 1; without it a few 16-byte pieces per tensor come out wrong)
+        if constexpr (GGQ_PLAIN_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
+        else if constexpr (GGQ_PLAIN_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
     }
 }
 
