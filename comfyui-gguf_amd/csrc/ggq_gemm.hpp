@@ -54,17 +54,17 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 #define GGQ_GT_DMA 1        /* x tiles and packed spans by LDS-DMA where the second staging buffer fits (0 = through registers everywhere); A/B builds */
 #endif
 #ifndef GGQ_GT_PINGPONG
-#define GGQ_GT_PINGPONG 1   /* the two waves of a SIMD run decode and MFMAs in opposite order: 1 = two halves per K-step, 2 = four sub-phases with the
-                               fragment reads requested first (0 = same order in both waves); A/B builds */
+#define GGQ_GT_PINGPONG 1   /* the waves of a SIMD alternate the order of decode and MFMAs (0 = same order in all waves); A/B builds */
 #endif
 
 GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) & 1u); }
 
-template <class F> struct GemmGeom {
+template <class F, int WM = 2> struct GemmGeom {
     using G = MfmaGeom<F>;
+    static constexpr int THREADS = WM * 4 * 64;                                  // WM x 4 waves
     static constexpr int UNITS = GT_BN * G::U;                                   // 16-byte units of one staged span
-    static constexpr int NUW = (UNITS + GT_THREADS - 1) / GT_THREADS;            // units per thread
-    static constexpr int STAGING = NUW * GT_THREADS * 16;                        // LDS bytes (>= 256 * ROW_STRIDE)
+    static constexpr int NUW = (UNITS + THREADS - 1) / THREADS;                  // units per thread
+    static constexpr int STAGING = NUW * THREADS * 16;                           // LDS bytes (>= 256 * ROW_STRIDE)
     // DMA: x tiles and packed spans go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass); the
     // asynchronous fill needs a SECOND staging buffer, which fits for every format but the two fattest (Q6_K 2 x 56 KiB, Q8_0 2 x 68 KiB):
     // those keep the register path.
@@ -78,14 +78,23 @@ GGQ_DEV void dma16(const GGQ_GLOBAL uint8_t* src, uint8_t* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const GGQ_GLOBAL void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <class F, int OUT>
-__global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
-                                                          const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
-                                                          uint32_t m, uint32_t n_rows, uint32_t cols, uint32_t tiles_m, uint32_t tiles_n)
+// WM = waves along the rows of x: 2 (8 waves, each 128 x 64 of the tile: 128 accumulator registers, 2 waves per SIMD) or 4 (16 waves, each
+// 64 x 64: 64 accumulator registers, 128 registers per wave, FOUR waves per SIMD -- twice the wavefronts to hide each other's LDS and
+// barrier latency at 33 % more fragment reads per MFMA).
+template <class F, int OUT, int WM = 2>
+__global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+                                                        const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
+                                                        uint32_t m, uint32_t n_rows, uint32_t cols, uint32_t tiles_m, uint32_t tiles_n)
 {
     using G = MfmaGeom<F>;
-    using GG = GemmGeom<F>;
+    using GG = GemmGeom<F, WM>;
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only");
+    static_assert(WM == 2 || WM == 4, "8 or 16 waves");
+    constexpr int THREADS = GG::THREADS;
+    constexpr int MT = 8 / WM;                       // 32-row blocks of x per wave
+    constexpr int TPR = THREADS / 256;               // decoding threads per weight row
+    constexpr int CPT = 4 / TPR;                     // chunks (8 weights) per thread per K-step
+    constexpr int XU = 1024 / THREADS;               // 16-byte units of the x tile per thread per K-step
     constexpr int CPB = F::BS / 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const xt = smem;                        // X[0], X[1]
@@ -110,11 +119,11 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
     const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
     const uint32_t n_spans = cols / MF_SPAN, n_steps = n_spans * GT_STEPS;
 
-    // ---- staging fill: unit u of the tile's span = (row u / U, 16-byte piece u % U); thread takes units t, t + 512, ...
+    // ---- staging fill: unit u of the tile's span = (row u / U, 16-byte piece u % U); thread takes units t, t + THREADS, ...
     auto fetch = [&](uint32_t span, u32x4 (&pf)[GG::NUW]) {
 #pragma unroll
         for (int u = 0; u < GG::NUW; u++) {
-            const uint32_t unit = t + (uint32_t)(GT_THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
+            const uint32_t unit = t + (uint32_t)(THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
             const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
             const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
@@ -126,31 +135,30 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
     auto dma_span = [&](uint32_t span, uint32_t buf) {
 #pragma unroll
         for (int u = 0; u < GG::NUW; u++) {
-            const uint32_t unit = t + (uint32_t)(GT_THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
+            const uint32_t unit = t + (uint32_t)(THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
             const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
             const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
             if (ur < (uint32_t)GT_BN && uu * 16u < a + (uint32_t)G::SPAN_BYTES)
-                dma16(packed + (off - a) + uu * 16u, stg + buf * (uint32_t)GG::STAGING + ((uint32_t)wave * 64u + (uint32_t)(GT_THREADS * u)) * 16u);
+                dma16(packed + (off - a) + uu * 16u, stg + buf * (uint32_t)GG::STAGING + ((uint32_t)wave * 64u + (uint32_t)(THREADS * u)) * 16u);
         }
     };
     auto stage = [&](const u32x4 (&pf)[GG::NUW]) {
 #pragma unroll
-        for (int u = 0; u < GG::NUW; u++) *reinterpret_cast<u32x4*>(stg + (t + (uint32_t)(GT_THREADS * u)) * 16u) = pf[u];
+        for (int u = 0; u < GG::NUW; u++) *reinterpret_cast<u32x4*>(stg + (t + (uint32_t)(THREADS * u)) * 16u) = pf[u];
     };
 
-    // ---- weight decode: thread -> (row t / 2, chunks 2 (t & 1), 2 (t & 1) + 1 of the K-step)
-    const uint32_t drow = t >> 1, dc0 = (t & 1u) * 2u;
+    // ---- weight decode: thread -> (row t / TPR, CPT consecutive chunks of the K-step's four)
+    const uint32_t drow = t / (uint32_t)TPR, dc0 = (t % (uint32_t)TPR) * (uint32_t)CPT;
     const uint32_t wrow = (n0 + drow < n_rows) ? n0 + drow : n_rows - 1;
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
     const uint32_t dswz = gt_swz(drow);
-    auto decode = [&](uint32_t step, uint8_t* wdst, int which = -1) {
+    auto decode = [&](uint32_t step, uint8_t* wdst) {
         const uint32_t span = step / GT_STEPS, ks = step % GT_STEPS;
         const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
         const uint8_t* wspan = stg + (GG::DMA ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            if (which >= 0 && which != s) continue;                                // (compile-time after inlining) one chunk, or both
+        for (int s = 0; s < CPT; s++) {
             const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
             const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, (int)(j % CPB));
             uint32_t w[4];
@@ -159,71 +167,65 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
         }
     };
 
-    // ---- x tile: thread -> rows t / 4 and t / 4 + 128, 16-byte piece t % 4
-    const uint32_t xrow = t >> 2, xpc = t & 3u;
-    const GGQ_GLOBAL uint8_t* xsrc[2];
-    uint32_t xdst[2];
+    // ---- x tile: unit u = t + THREADS i -> (row u / 4, 16-byte piece u % 4)
+    const uint32_t xpc = t & 3u;
+    const GGQ_GLOBAL uint8_t* xsrc[XU];
+    uint32_t xdst[XU];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t row = xrow + 128u * (uint32_t)i, mr = m0 + row;
+    for (int i = 0; i < XU; i++) {
+        const uint32_t row = (t >> 2) + (uint32_t)(THREADS / 4 * i), mr = m0 + row;
         xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + xpc * 16u;
         xdst[i] = row * GT_PITCH + ((xpc ^ gt_swz(row)) * 16u);
     }
-    auto xload = [&](uint32_t step, u32x4 (&xr)[2]) {
+    auto xload = [&](uint32_t step, u32x4 (&xr)[XU]) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * GT_PITCH);
+        for (int i = 0; i < XU; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * GT_PITCH);
     };
-    // ... or by LDS-DMA: the LDS image is lane-linear (row t / 4, piece t % 4), so the XOR swizzle goes on the SOURCE piece
+    // ... or by LDS-DMA: the LDS image is lane-linear (row u / 4, piece u % 4), so the XOR swizzle goes on the SOURCE piece
     auto xdma = [&](uint32_t step, uint8_t* xd) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t row = xrow + 128u * (uint32_t)i;
+        for (int i = 0; i < XU; i++) {
+            const uint32_t row = (t >> 2) + (uint32_t)(THREADS / 4 * i);
             const GGQ_GLOBAL uint8_t* src = xsrc[i] - xpc * 16u + ((xpc ^ gt_swz(row)) * 16u) + (uint64_t)step * GT_PITCH;
-            dma16(src, xd + ((uint32_t)wave * 64u + (uint32_t)(GT_THREADS * i)) * 16u);
+            dma16(src, xd + ((uint32_t)wave * 64u + (uint32_t)(THREADS * i)) * 16u);
         }
     };
-    auto xstore = [&](const u32x4 (&xr)[2], uint8_t* xd) {
+    auto xstore = [&](const u32x4 (&xr)[XU], uint8_t* xd) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) *reinterpret_cast<u32x4*>(xd + xdst[i]) = xr[i];
+        for (int i = 0; i < XU; i++) *reinterpret_cast<u32x4*>(xd + xdst[i]) = xr[i];
     };
 
-    // ---- MFMA roles: wave -> (wm = wave / 4: rows of x [128 wm, +128), wn = wave % 4: output columns [64 wn, +64))
+    // ---- MFMA roles: wave -> (wm = wave / 4: rows of x [32 MT wm, +32 MT), wn = wave % 4: output columns [64 wn, +64))
     const uint32_t wm = (uint32_t)wave >> 2, wn = (uint32_t)wave & 3u;
     const uint32_t r32 = lane & 31u, hk = lane >> 5, fswz = gt_swz(r32);
-    f32x16 acc[2][4];
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[nt][mt][i] = 0.0f;
 
-    // one k-slice of 16: the wave's 2 weight fragments and 4 x fragments (one ds_read_b128 each), then its 8 MFMAs
-    auto frags = [&](const uint8_t* xs, const uint8_t* ws, int kk, u32x4 (&wa)[2], u32x4 (&xb)[4]) {
-        const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + (128u * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
-    };
-    auto mma8 = [&](const u32x4 (&wa)[2], const u32x4 (&xb)[4]) {
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
-    };
+    // one k-slice of 16: the wave's 2 weight fragments and MT x fragments (one ds_read_b128 each), then its 2 MT MFMAs
     auto mma = [&](const uint8_t* xs, const uint8_t* ws) {
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
-            u32x4 wa[2], xb[4];
-            frags(xs, ws, kk, wa, xb);
-            mma8(wa, xb);
+            const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
+            u32x4 wa[2], xb[MT];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + ((uint32_t)(32 * MT) * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
         }
     };
 
     // ---- prologue: span 0 staged, tile 0 of both operands in buffer 0
     u32x4 pf[GG::DMA ? 1 : GG::NUW];
-    u32x4 xr[2];
+    u32x4 xr[XU];
     auto dma_fence = [&]() {
         if constexpr (GG::DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every LDS-DMA of this wave has landed; the barrier then publishes it
         __syncthreads();
@@ -248,12 +250,12 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
         __syncthreads();
     }
 
-    // ---- main loop.  One K-step = [decode weight tile t+1 -> W[next]] + [MFMAs on X[cur], W[cur]] + [x registers -> X[next], loads of
-    // tile t+2] + one s_barrier.  decode(t + 1) and mma(t) are independent, so a wave may run them in either order: the two waves that
-    // share a SIMD (w and w + 4: a workgroup's waves are dealt to the four SIMDs cyclically) take OPPOSITE orders (PONG) -- one feeds the
-    // matrix pipe while the other keeps the VALU busy with the decode, then they swap; sched_barrier keeps the compiler from mixing the
-    // halves back together.  Each order is its own copy of the loop (a wave-uniform branch around the whole loop, not inside it: the
-    // 128 accumulator registers never meet in a phi); steps come in pairs so that the buffer parity is a compile-time constant.
+    // ---- main loop.  One K-step = [decode weight tile t+1 -> W[next]] + [MFMAs on X[cur], W[cur]] + [x tile t+1 -> X[next]] + one s_barrier.
+    // decode(t + 1) and mma(t) are independent, so a wave may run them in either order: the waves that share a SIMD (w, w + 4, w + 8, ...: a
+    // workgroup's waves are dealt to the four SIMDs cyclically) take ALTERNATING orders (PONG) -- while one feeds the matrix pipe another keeps
+    // the VALU busy with the decode, then they swap; sched_barrier keeps the compiler from mixing the halves back together.  Each order is its
+    // own copy of the loop (a wave-uniform branch around the whole loop, not inside it: the accumulator registers never meet in a phi); steps
+    // come in pairs so that the buffer parity is a compile-time constant.
     auto kstep = [&](uint32_t step, auto parity_tag, auto pong_tag, auto decode_tag) {
         constexpr int P = decltype(parity_tag)::value;
         constexpr bool PONG = decltype(pong_tag)::value, DECODE = decltype(decode_tag)::value;
@@ -274,37 +276,11 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
             }
         }
         if constexpr (GG::DMA) {
-            // x tile of step + 2 ... no: of step + 1, straight into the other x buffer (free since the previous barrier); it has the
-            // whole K-step to land
-            if (step + 1 < n_steps) xdma(step + 1 + 0u, xnxt);
+            // x tile of step + 1 straight into the other x buffer (free since the previous barrier); it has the whole K-step to land
+            if (step + 1 < n_steps) xdma(step + 1, xnxt);
         }
         if constexpr (!DECODE) {
             mma(xcur, wcur);
-        } else if constexpr (GGQ_GT_PINGPONG == 2 && GG::DMA) {     // (the register-staged formats have no room for two fragment sets)
-            // four sub-phases per K-step: the fragments of the first k-slice are requested FIRST (they land while the first decode or
-            // the partner's MFMAs run), then [decode one chunk | 8 MFMAs] twice, the two waves of a SIMD in opposite order
-            u32x4 wa0[2], xb0[4], wa1[2], xb1[4];
-            frags(xcur, wcur, 0, wa0, xb0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PONG) {
-                frags(xcur, wcur, 1, wa1, xb1);
-                mma8(wa0, xb0);
-                __builtin_amdgcn_sched_barrier(0);
-                decode(step + 1, wnxt, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma8(wa1, xb1);
-                __builtin_amdgcn_sched_barrier(0);
-                decode(step + 1, wnxt, 1);
-            } else {
-                decode(step + 1, wnxt, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                frags(xcur, wcur, 1, wa1, xb1);
-                mma8(wa0, xb0);
-                __builtin_amdgcn_sched_barrier(0);
-                decode(step + 1, wnxt, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma8(wa1, xb1);
-            }
         } else if constexpr (PONG && GGQ_GT_PINGPONG) {
             mma(xcur, wcur);
             __builtin_amdgcn_sched_barrier(GGQ_GT_CROSS);
@@ -336,14 +312,14 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
         kstep(step, T0{}, pong_tag, std::true_type{});
         kstep(step + 1, T1{}, pong_tag, std::false_type{});        // the last step has nothing left to decode
     };
-    if (wave >= 4) main_loop(std::true_type{});
+    if ((wave >> 2) & 1) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
-    // ---- epilogue: bias, cast, transpose through LDS (wave-private 8 KiB: 64 rows of x  x  64 columns), full-line stores.
+    // ---- epilogue: bias, cast, transpose through LDS (wave-private 4 KiB: 32 rows of x  x  64 columns), full-line stores.
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here
     // row = output column n inside its 32-block, col = row of x inside its 32-block.
-    uint8_t* const ep = smem + wave * 8192;
-    const uint32_t nbase = n0 + 64u * wn, mbase = m0 + 128u * wm;
+    uint8_t* const ep = smem + wave * 4096;
+    const uint32_t nbase = n0 + 64u * wn, mbase = m0 + (uint32_t)(32 * MT) * wm;
     float bias[2][4][4];
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
@@ -362,30 +338,25 @@ __global__ __launch_bounds__(GT_THREADS) void linear_tile(const uint8_t* __restr
             }
         }
 #pragma unroll
-    for (int rd = 0; rd < 2; rd++) {
+    for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
-        for (int mh = 0; mh < 2; mh++) {
-            const int mt = 2 * rd + mh;
-            const uint32_t ml = 32u * (uint32_t)mh + r32;                            // row of x inside the 64-row round
+        for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float v0 = acc[nt][mt][4 * q + 0] + bias[nt][q][0], v1 = acc[nt][mt][4 * q + 1] + bias[nt][q][1];
-                    const float v2 = acc[nt][mt][4 * q + 2] + bias[nt][q][2], v3 = acc[nt][mt][4 * q + 3] + bias[nt][q][3];
-                    u32x2 o;
-                    if constexpr (OUT == OUT_F16) o = u32x2{pack_f16(v0, v1), pack_f16(v2, v3)};
-                    else o = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
-                    const uint32_t p = 4u * (uint32_t)nt + (uint32_t)q;              // 16-byte piece = columns 8p .. 8p+7
-                    *reinterpret_cast<u32x2*>(ep + ml * 128u + ((p ^ (ml & 7u)) * 16u) + 8u * hk) = o;
-                }
-        }
+            for (int q = 0; q < 4; q++) {
+                const float v0 = acc[nt][mt][4 * q + 0] + bias[nt][q][0], v1 = acc[nt][mt][4 * q + 1] + bias[nt][q][1];
+                const float v2 = acc[nt][mt][4 * q + 2] + bias[nt][q][2], v3 = acc[nt][mt][4 * q + 3] + bias[nt][q][3];
+                u32x2 o;
+                if constexpr (OUT == OUT_F16) o = u32x2{pack_f16(v0, v1), pack_f16(v2, v3)};
+                else o = u32x2{pack_bf16(v0, v1), pack_bf16(v2, v3)};
+                const uint32_t p = 4u * (uint32_t)nt + (uint32_t)q;              // 16-byte piece = columns 8p .. 8p+7
+                *reinterpret_cast<u32x2*>(ep + r32 * 128u + ((p ^ (r32 & 7u)) * 16u) + 8u * hk) = o;
+            }
         wave_sync();
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 4; i++) {
             const uint32_t row = (lane >> 3) + 8u * (uint32_t)i, p = lane & 7u;
             const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * 128u + ((p ^ (row & 7u)) * 16u));
-            const uint32_t mr = mbase + 64u * (uint32_t)rd + row, nc = nbase + 8u * p;
+            const uint32_t mr = mbase + 32u * (uint32_t)mt + row, nc = nbase + 8u * p;
             if (mr < m && nc < n_rows) gstore<false>((gptr)y_ + ((uint64_t)mr * n_rows + nc) * 2, v);       // n_rows % 8 == 0 (host)
         }
         wave_sync();

@@ -18,6 +18,9 @@ using namespace ggq;
 typedef hipError_t (*lin_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, hipStream_t);
 
 constexpr int MAX_DEVICES = 64;
+#ifndef GGQ_TILE_WM_DEFAULT
+#define GGQ_TILE_WM_DEFAULT 2
+#endif
 
 // compute units of the current device, asked once per device (the launch path runs per layer per step)
 uint32_t compute_units(int dev)
@@ -83,25 +86,38 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
-// ---- the shared-tile kernel (ggq_gemm.hpp): 256 rows of x  x  256 output columns per workgroup, weights decoded once per workgroup
-template <class F, int OUT>
-hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+// ---- the shared-tile kernel (ggq_gemm.hpp): 256 rows of x  x  256 output columns per workgroup, weights decoded once per workgroup.
+// WM = 2: 8 waves (128 x 64 outputs each, 2 waves per SIMD); WM = 4: 16 waves (64 x 64 each, 4 waves per SIMD).  GGQ_TILE_WM (environment, read
+// once: A/B runs) picks; EXPERIMENTS.md A2c has the comparison.
+template <class F, int OUT, int WM>
+hipError_t launch_tile_wm(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
-    constexpr uint32_t lds = (uint32_t)GemmGeom<F>::LDS_BYTES;
+    constexpr uint32_t lds = (uint32_t)GemmGeom<F, WM>::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     int dev = 0;
     (void)hipGetDevice(&dev);
     static std::atomic<uint64_t> raised{0};          // > 64 KiB of dynamic LDS: raise the limit once per device for this instantiation
     const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile<F, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile<F, OUT, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
     const uint32_t tiles_m = (m + GT_BM - 1) / GT_BM, tiles_n = (rows + GT_BN - 1) / GT_BN;
-    hipLaunchKernelGGL((linear_tile<F, OUT>), dim3(tiles_m * tiles_n), dim3(GT_THREADS), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
-                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, tiles_m, tiles_n);
+    hipLaunchKernelGGL((linear_tile<F, OUT, WM>), dim3(tiles_m * tiles_n), dim3(GemmGeom<F, WM>::THREADS), lds, s, static_cast<const uint8_t*>(packed),
+                       static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, tiles_m, tiles_n);
     return hipGetLastError();
+}
+
+template <class F, int OUT>
+hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    static const int wm = [] {
+        const char* e = getenv("GGQ_TILE_WM");
+        return (e && *e == '4') ? 4 : ((e && *e == '2') ? 2 : GGQ_TILE_WM_DEFAULT);
+    }();
+    if (wm == 4) return launch_tile_wm<F, OUT, 4>(packed, x, bias, y, m, rows, cols, s);
+    return launch_tile_wm<F, OUT, 2>(packed, x, bias, y, m, rows, cols, s);
 }
 
 // ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp): built, correct, 13 % SLOWER than the K-step-32 kernel (EXPERIMENTS.md
