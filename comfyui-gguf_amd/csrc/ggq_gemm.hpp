@@ -53,6 +53,9 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 #ifndef GGQ_GT_DMA
 #define GGQ_GT_DMA 1        /* x tiles and packed spans by LDS-DMA where the second staging buffer fits (0 = through registers everywhere); A/B builds */
 #endif
+#ifndef GGQ_GT_XRING
+#define GGQ_GT_XRING 1      /* a third x buffer where it fits: x tiles requested two K-steps ahead (0 = one step ahead); A/B builds */
+#endif
 #ifndef GGQ_GT_PINGPONG
 #define GGQ_GT_PINGPONG 1   /* the waves of a SIMD alternate the order of decode and MFMAs (0 = same order in all waves); A/B builds */
 #endif
@@ -69,7 +72,10 @@ template <class F, int WM = 2> struct GemmGeom {
     // asynchronous fill needs a SECOND staging buffer, which fits for every format but the two fattest (Q6_K 2 x 56 KiB, Q8_0 2 x 68 KiB):
     // those keep the register path.
     static constexpr bool DMA = GGQ_GT_DMA && 4 * GT_TILE + 2 * STAGING <= 160 * 1024;
-    static constexpr int LDS_BYTES = 4 * GT_TILE + (DMA ? 2 : 1) * STAGING;
+    // XR = x tiles in flight: with LDS-DMA and room for a THIRD x buffer the x tile of step t + 2 is requested at step t and only the one of
+    // step t + 1 is waited for (counted s_waitcnt vmcnt + raw s_barrier: the DMA has two K-steps to land instead of one)
+    static constexpr int XR = (DMA && GGQ_GT_XRING && 5 * GT_TILE + 2 * STAGING <= 160 * 1024) ? 3 : 2;
+    static constexpr int LDS_BYTES = (2 + XR) * GT_TILE + (DMA ? 2 : 1) * STAGING;
 };
 
 // one 16-byte piece per lane, global -> LDS without passing through registers; the LDS address is wave-uniform base + 16 * lane
@@ -97,9 +103,10 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     constexpr int XU = 1024 / THREADS;               // 16-byte units of the x tile per thread per K-step
     constexpr int CPB = F::BS / 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* const xt = smem;                        // X[0], X[1]
-    uint8_t* const wt = smem + 2 * GT_TILE;          // W[0], W[1]
-    uint8_t* const stg = smem + 4 * GT_TILE;
+    constexpr int XR = GG::XR;
+    uint8_t* const xt = smem;                        // X[0 .. XR)
+    uint8_t* const wt = smem + XR * GT_TILE;         // W[0], W[1]
+    uint8_t* const stg = smem + (XR + 2) * GT_TILE;
 
     const uint32_t t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(t >> 6));
@@ -230,13 +237,21 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         if constexpr (GG::DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every LDS-DMA of this wave has landed; the barrier then publishes it
         __syncthreads();
     };
+    // the fence of a K-step with XR = 3: the x tile requested THIS step (the XU newest DMAs) may stay in flight; everything older -- the x tile
+    // the next step reads, a packed span -- has landed.  Raw s_barrier: __syncthreads() would make hipcc drain vmcnt to 0 behind our back.
+    auto ring_fence = [&]() {
+        if constexpr (XU == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     if constexpr (GG::DMA) {
         dma_span(0u, 0u);
         xdma(0u, xt);
         dma_fence();
         if (n_spans > 1) dma_span(1u, 1u);
         decode(0u, wt);
-        if (n_steps > 1) xdma(1u, xt + GT_TILE);
+        xdma(n_steps > 1 ? 1u : 0u, xt + GT_TILE);
         dma_fence();
     } else {
         fetch(0u, pf);
@@ -259,9 +274,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     auto kstep = [&](uint32_t step, auto parity_tag, auto pong_tag, auto decode_tag) {
         constexpr int P = decltype(parity_tag)::value;
         constexpr bool PONG = decltype(pong_tag)::value, DECODE = decltype(decode_tag)::value;
-        uint8_t* const xcur = xt + P * GT_TILE;
+        uint8_t* const xcur = xt + (XR == 3 ? step % 3u : (uint32_t)P) * GT_TILE;
         uint8_t* const wcur = wt + P * GT_TILE;
-        uint8_t* const xnxt = xt + (P ^ 1) * GT_TILE;
+        uint8_t* const xnxt = xt + (XR == 3 ? (step + 2u) % 3u : (uint32_t)(P ^ 1)) * GT_TILE;    // XR = 3: the buffer of step + 2 (read last at step - 1)
         uint8_t* const wnxt = wt + (P ^ 1) * GT_TILE;
         if (DECODE && (step + 1) % GT_STEPS == 0) {
             // the next K-step opens a new span: every decode of the old one finished before the previous barrier
@@ -275,7 +290,10 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
                 if (span + 1 < n_spans) fetch(span + 1, pf);
             }
         }
-        if constexpr (GG::DMA) {
+        if constexpr (GG::DMA && XR == 3) {
+            // x tile of step + 2 (clamped at the end: a harmless re-read into a buffer nobody reads any more): two K-steps to land
+            if constexpr (DECODE) xdma(step + 2 < n_steps ? step + 2 : n_steps - 1, xnxt);
+        } else if constexpr (GG::DMA) {
             // x tile of step + 1 straight into the other x buffer (free since the previous barrier); it has the whole K-step to land
             if (step + 1 < n_steps) xdma(step + 1, xnxt);
         }
@@ -292,7 +310,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 #endif
             mma(xcur, wcur);
         }
-        if constexpr (GG::DMA) {
+        if constexpr (GG::DMA && XR == 3) {
+            ring_fence();
+        } else if constexpr (GG::DMA) {
             dma_fence();
         } else {
             // x tile of the next step: registers -> LDS; then the loads of the step after (clamped at the end: a harmless re-read)
@@ -314,6 +334,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     };
     if ((wave >> 2) & 1) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (GG::DMA && XR == 3) dma_fence();           // nothing may still be landing in LDS when the epilogue reuses it
 
     // ---- epilogue: bias, cast, transpose through LDS (wave-private 4 KiB: 32 rows of x  x  64 columns), full-line stores.
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here
