@@ -7,24 +7,29 @@
 // "unpack once + hipBLASLt" beyond ~256 rows.  Here the decode is amortised the way a GEMM amortises its operand
 // loads: a workgroup owns a 256 x 256 output tile; per K-step of 32 it decodes its 256 x 32 weight tile ONCE -- 16 weights per
 // thread, the same `fields` / `quad_f16` (+ `.to(dtype)`) code as the dequant kernels, so the weights are the reference's values
-// bit for bit -- into LDS as fp16 / bf16, next to the 256 x 32 tile of x; all 8 waves then read MFMA fragments of both with
+// bit for bit -- into LDS as fp16 / bf16, next to the 256 x 32 tile of x; all 16 waves then read MFMA fragments of both with
 // ds_read_b128.  One decoded weight feeds 256 rows of x instead of 32..128.
 //
-// Shape of the work (8 waves, 512 threads, one workgroup per CU):
-//   * LDS: X[2] and W[2] tiles of 256 rows x 64 B (32 K-elements), double-buffered: 64 KiB; STAGING: the packed bytes of the
-//     tile's 256 weight rows for one 256-element span of K (one K-quant super-block / 8 legacy blocks per row: 36 KiB for Q4_K),
-//     filled with coalesced 16 B/lane loads, the next span's bytes in flight in registers meanwhile;
-//   * tile rows are 64 B; the 16-byte column is XOR-swizzled with ((row >> 3) & 3) ^ ((row >> 1) & 1): ds_read_b128 fragment reads
-//     (one row per lane, gfx950's four non-contiguous 16-lane groups, MI355X_MICROARCH.md LDS) and both writers -- x: 4 lanes per
-//     row; weights: 2 lanes per row, 2 chunks each -- are bank-conflict-free;
-//   * K-step t: [x tile t+1: global -> registers] [decode weight tile t+1 -> W[next]] [MFMAs on X[cur], W[cur]: 2 k-slices of 16,
-//     per wave 2 (n) x 4 (m) tiles of 32 x 32 = 16 v_mfma_f32_32x32x16] [x registers -> X[next]] one s_barrier.  The compiler
-//     interleaves the decode VALU work with the MFMAs; the two waves of a SIMD overlap each other's LDS traffic;
+// Shape of the work (16 waves = 1024 threads, four waves per SIMD, one workgroup per CU):
+//   * LDS: X[3] and W[2] tiles of 256 rows x 64 B (32 K-elements): 80 KiB; STAGING: the packed bytes of the tile's 256 weight rows for one
+//     span of K (one K-quant super-block = 256 elements; 4 blocks = 128 elements for the legacy formats), double-buffered where that fits
+//     (Q4_K 2 x 36 KiB) -- everything arrives by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): packed spans one span
+//     ahead, x tiles two K-steps ahead, waited for with a COUNTED s_waitcnt vmcnt and a raw s_barrier;
+//   * tile rows are 64 B; the 16-byte column is XOR-swizzled with ((row >> 3) & 3) ^ ((row >> 1) & 1) (for the DMA'd x tile on the SOURCE
+//     address, the LDS image of a DMA being lane-linear): ds_read_b128 fragment reads (one row per lane, gfx950's four non-contiguous 16-lane
+//     groups, MI355X_MICROARCH.md LDS) and the decode's ds_write_b128 (4 lanes per row) are bank-conflict-free;
+//   * K-step t: [DMA: x tile t+2] [decode weight tile t+1 -> W[next]: one chunk of 8 weights per thread] [MFMAs on X[t], W[t]: 2 k-slices of 16,
+//     per wave 2 (n) x 2 (m) tiles of 32 x 32 = 8 v_mfma_f32_32x32x16] one s_barrier.  The waves of a SIMD alternate the order of decode and
+//     MFMAs (ping-pong), so that the VALU and the matrix pipe of a SIMD have work at the same time;
 //   * MFMA operands: A = weights (i = output column n), B = x (j = row m): a lane's accumulator registers then hold FOUR CONSECUTIVE
 //     n of one row m, so the epilogue packs 8-byte pieces, transposes through LDS (XOR-swizzled, wave-private) and stores full
 //     128-byte lines of y with 16 B per lane;
 //   * workgroup -> tile mapping: XCD x (workgroup b runs on XCD b % 8) takes a contiguous eighth of the tiles in column-major
 //     order, so the tiles that run together in one XCD share weight panels (read from HBM once) and x panels in that XCD's L2.
+//
+// Where the time goes (EXPERIMENTS.md A2c): a K-step without the decode takes 1600 cycles, without the MFMAs 1400 (VALU-issue-bound: the price
+// of reproducing the reference's fp16 values), together 2100 -- VALU issue and the matrix pipe mostly in series; 0.82-0.85 PFLOP/s at 4608 rows,
+// behind unpack + hipBLASLt, hence opt-in and off the default path above ~256 rows.
 //
 // Numerics: weights = the reference's values bit for bit; products exact in fp32; fp32 accumulation in k order inside the MFMA,
 // K-steps in order, no K split (deterministic).  Like any GEMM against another GEMM the result differs from hipBLASLt's by
@@ -42,7 +47,7 @@ constexpr int GT_BM = 256, GT_BN = 256, GT_BK = 32;
 constexpr int GT_WAVES = 8, GT_THREADS = GT_WAVES * 64;
 constexpr int GT_PITCH = GT_BK * 2;                      // bytes per tile row
 constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 KiB
-constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged span (8)
+
 #ifndef GGQ_GT_SCHED
 #define GGQ_GT_SCHED 0      /* VALU instructions asked for behind every MFMA of a K-step (0 = leave the order to the compiler); A/B builds */
 #endif
@@ -50,8 +55,8 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 #define GGQ_GT_CROSS 0x100  /* what may be scheduled ACROSS the line between the two halves of a K-step: LDS reads (so the second half's operands
                                are already on their way while the first half runs); 0 = nothing; A/B builds */
 #endif
-#ifndef GGQ_GT_DMA
-#define GGQ_GT_DMA 1        /* x tiles and packed spans by LDS-DMA where the second staging buffer fits (0 = through registers everywhere); A/B builds */
+#ifndef GGQ_GT_ABLATE
+#define GGQ_GT_ABLATE 0     /* timing ablations for EXPERIMENTS.md (wrong results!): 1 = K-steps without the decode, 2 = without the MFMAs */
 #endif
 #ifndef GGQ_GT_XRING
 #define GGQ_GT_XRING 1      /* a third x buffer where it fits: x tiles requested two K-steps ahead (0 = one step ahead); A/B builds */
@@ -62,20 +67,31 @@ constexpr int GT_STEPS = MF_SPAN / GT_BK;                // K-steps per staged s
 
 GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) & 1u); }
 
-template <class F, int WM = 2> struct GemmGeom {
-    using G = MfmaGeom<F>;
+// How much of K is staged at a time: one super-block (256 elements) for the K-quants -- `fields` wants the whole block -- and 4 blocks (128
+// elements) for the 32-element legacy formats, whose staging then fits twice beside the operand tiles (Q8_0: 2 x 40 KiB) so that they too are
+// filled by LDS-DMA instead of through registers.
+template <class F> struct TileSpan {
+    static constexpr int SPAN = (F::BS == 32) ? 128 : 256;
+    static constexpr int STEPS = SPAN / GT_BK;                                    // K-steps per staged span
+    static constexpr int SPAN_BYTES = SPAN / F::BS * F::TS;
+    // a span may start at any 2-byte boundary (Q6_K 210 B, Q3_K 110 B, 4 x 34 B, ...): every row keeps its own leading misalignment
+    static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0;
+    static constexpr int U = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;         // 16-byte load units per row
+    static constexpr int ROW_STRIDE = U * 16;
+};
+
+template <class F, int WM = 4> struct GemmGeom {
+    using G = TileSpan<F>;
     static constexpr int THREADS = WM * 4 * 64;                                  // WM x 4 waves
     static constexpr int UNITS = GT_BN * G::U;                                   // 16-byte units of one staged span
     static constexpr int NUW = (UNITS + THREADS - 1) / THREADS;                  // units per thread
     static constexpr int STAGING = NUW * THREADS * 16;                           // LDS bytes (>= 256 * ROW_STRIDE)
-    // DMA: x tiles and packed spans go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass); the
-    // asynchronous fill needs a SECOND staging buffer, which fits for every format but the two fattest (Q6_K 2 x 56 KiB, Q8_0 2 x 68 KiB):
-    // those keep the register path.
-    static constexpr bool DMA = GGQ_GT_DMA && 4 * GT_TILE + 2 * STAGING <= 160 * 1024;
-    // XR = x tiles in flight: with LDS-DMA and room for a THIRD x buffer the x tile of step t + 2 is requested at step t and only the one of
-    // step t + 1 is waited for (counted s_waitcnt vmcnt + raw s_barrier: the DMA has two K-steps to land instead of one)
-    static constexpr int XR = (DMA && GGQ_GT_XRING && 5 * GT_TILE + 2 * STAGING <= 160 * 1024) ? 3 : 2;
-    static constexpr int LDS_BYTES = (2 + XR) * GT_TILE + (DMA ? 2 : 1) * STAGING;
+    // XR = x tiles in flight: with room for a THIRD x buffer the x tile of step t + 2 is requested at step t and only the one of step t + 1 is
+    // waited for.  DBUF: the packed span after the current one lands in a second staging buffer while this one is decoded; where two do not
+    // fit (Q6_K: 2 x 56 KiB) the single buffer is refilled at the span boundary and the workgroup waits for it once per 8 K-steps.
+    static constexpr bool DBUF = 4 * GT_TILE + 2 * STAGING <= 160 * 1024;
+    static constexpr int XR = (GGQ_GT_XRING && 5 * GT_TILE + (DBUF ? 2 : 1) * STAGING <= 160 * 1024) ? 3 : 2;
+    static constexpr int LDS_BYTES = (2 + XR) * GT_TILE + (DBUF ? 2 : 1) * STAGING;
 };
 
 // one 16-byte piece per lane, global -> LDS without passing through registers; the LDS address is wave-uniform base + 16 * lane
@@ -87,12 +103,12 @@ GGQ_DEV void dma16(const GGQ_GLOBAL uint8_t* src, uint8_t* lds_wave_base)
 // WM = waves along the rows of x: 2 (8 waves, each 128 x 64 of the tile: 128 accumulator registers, 2 waves per SIMD) or 4 (16 waves, each
 // 64 x 64: 64 accumulator registers, 128 registers per wave, FOUR waves per SIMD -- twice the wavefronts to hide each other's LDS and
 // barrier latency at 33 % more fragment reads per MFMA).
-template <class F, int OUT, int WM = 2>
+template <class F, int OUT, int WM = 4>
 __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                         const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
                                                         uint32_t m, uint32_t n_rows, uint32_t cols, uint32_t tiles_m, uint32_t tiles_n)
 {
-    using G = MfmaGeom<F>;
+    using G = TileSpan<F>;
     using GG = GemmGeom<F, WM>;
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only");
     static_assert(WM == 2 || WM == 4, "8 or 16 waves");
@@ -124,21 +140,12 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 
     const gcptr packed = (gcptr)packed_;
     const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
-    const uint32_t n_spans = cols / MF_SPAN, n_steps = n_spans * GT_STEPS;
+    constexpr uint32_t STEPS = (uint32_t)G::STEPS;
+    const uint32_t n_spans = cols / (uint32_t)G::SPAN, n_steps = n_spans * STEPS;
 
-    // ---- staging fill: unit u of the tile's span = (row u / U, 16-byte piece u % U); thread takes units t, t + THREADS, ...
-    auto fetch = [&](uint32_t span, u32x4 (&pf)[GG::NUW]) {
-#pragma unroll
-        for (int u = 0; u < GG::NUW; u++) {
-            const uint32_t unit = t + (uint32_t)(THREADS * u), ur = unit / (uint32_t)G::U, uu = unit - ur * (uint32_t)G::U;
-            const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
-            const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
-            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
-            // the last unit of a row may reach past the row's span by < 16 bytes inside its aligned 16-byte unit: same page, never faults
-            pf[u] = (ur < (uint32_t)GT_BN && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
-        }
-    };
-    // the same units by LDS-DMA into staging buffer `buf` (lanes whose unit lies outside the span are masked: those bytes are never read)
+    // ---- staging fill by LDS-DMA: unit u of the tile's span = (row u / U, 16-byte piece u % U); thread takes units t, t + THREADS, ...
+    // (lanes whose unit lies outside the span are masked: those bytes are never read; the last unit of a row may reach past the row's span by
+    // < 16 bytes inside its aligned 16-byte unit: same page, never faults)
     auto dma_span = [&](uint32_t span, uint32_t buf) {
 #pragma unroll
         for (int u = 0; u < GG::NUW; u++) {
@@ -150,20 +157,15 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
                 dma16(packed + (off - a) + uu * 16u, stg + buf * (uint32_t)GG::STAGING + ((uint32_t)wave * 64u + (uint32_t)(THREADS * u)) * 16u);
         }
     };
-    auto stage = [&](const u32x4 (&pf)[GG::NUW]) {
-#pragma unroll
-        for (int u = 0; u < GG::NUW; u++) *reinterpret_cast<u32x4*>(stg + (t + (uint32_t)(THREADS * u)) * 16u) = pf[u];
-    };
-
     // ---- weight decode: thread -> (row t / TPR, CPT consecutive chunks of the K-step's four)
     const uint32_t drow = t / (uint32_t)TPR, dc0 = (t % (uint32_t)TPR) * (uint32_t)CPT;
     const uint32_t wrow = (n0 + drow < n_rows) ? n0 + drow : n_rows - 1;
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
     const uint32_t dswz = gt_swz(drow);
     auto decode = [&](uint32_t step, uint8_t* wdst) {
-        const uint32_t span = step / GT_STEPS, ks = step % GT_STEPS;
+        const uint32_t span = step / STEPS, ks = step % STEPS;
         const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
-        const uint8_t* wspan = stg + (GG::DMA ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
+        const uint8_t* wspan = stg + (GG::DBUF ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
 #pragma unroll
         for (int s = 0; s < CPT; s++) {
             const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
@@ -174,32 +176,17 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         }
     };
 
-    // ---- x tile: unit u = t + THREADS i -> (row u / 4, 16-byte piece u % 4)
-    const uint32_t xpc = t & 3u;
+    // ---- x tile by LDS-DMA: unit u = t + THREADS i -> (row u / 4, 16-byte piece u % 4); the LDS image is lane-linear, so the XOR swizzle goes
+    // on the SOURCE piece
     const GGQ_GLOBAL uint8_t* xsrc[XU];
-    uint32_t xdst[XU];
 #pragma unroll
     for (int i = 0; i < XU; i++) {
         const uint32_t row = (t >> 2) + (uint32_t)(THREADS / 4 * i), mr = m0 + row;
-        xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + xpc * 16u;
-        xdst[i] = row * GT_PITCH + ((xpc ^ gt_swz(row)) * 16u);
+        xsrc[i] = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (((t & 3u) ^ gt_swz(row)) * 16u);
     }
-    auto xload = [&](uint32_t step, u32x4 (&xr)[XU]) {
-#pragma unroll
-        for (int i = 0; i < XU; i++) xr[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + (uint64_t)step * GT_PITCH);
-    };
-    // ... or by LDS-DMA: the LDS image is lane-linear (row u / 4, piece u % 4), so the XOR swizzle goes on the SOURCE piece
     auto xdma = [&](uint32_t step, uint8_t* xd) {
 #pragma unroll
-        for (int i = 0; i < XU; i++) {
-            const uint32_t row = (t >> 2) + (uint32_t)(THREADS / 4 * i);
-            const GGQ_GLOBAL uint8_t* src = xsrc[i] - xpc * 16u + ((xpc ^ gt_swz(row)) * 16u) + (uint64_t)step * GT_PITCH;
-            dma16(src, xd + ((uint32_t)wave * 64u + (uint32_t)(THREADS * i)) * 16u);
-        }
-    };
-    auto xstore = [&](const u32x4 (&xr)[XU], uint8_t* xd) {
-#pragma unroll
-        for (int i = 0; i < XU; i++) *reinterpret_cast<u32x4*>(xd + xdst[i]) = xr[i];
+        for (int i = 0; i < XU; i++) dma16(xsrc[i] + (uint64_t)step * GT_PITCH, xd + ((uint32_t)wave * 64u + (uint32_t)(THREADS * i)) * 16u);
     };
 
     // ---- MFMA roles: wave -> (wm = wave / 4: rows of x [32 MT wm, +32 MT), wn = wave % 4: output columns [64 wn, +64))
@@ -230,11 +217,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         }
     };
 
-    // ---- prologue: span 0 staged, tile 0 of both operands in buffer 0
-    u32x4 pf[GG::DMA ? 1 : GG::NUW];
-    u32x4 xr[XU];
+    // ---- prologue: span 0 staged, x tiles 0 and 1 requested, weight tile 0 decoded
     auto dma_fence = [&]() {
-        if constexpr (GG::DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every LDS-DMA of this wave has landed; the barrier then publishes it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every LDS-DMA of this wave has landed; the barrier then publishes it
         __syncthreads();
     };
     // the fence of a K-step with XR = 3: the x tile requested THIS step (the XU newest DMAs) may stay in flight; everything older -- the x tile
@@ -245,25 +230,13 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    if constexpr (GG::DMA) {
-        dma_span(0u, 0u);
-        xdma(0u, xt);
-        dma_fence();
-        if (n_spans > 1) dma_span(1u, 1u);
-        decode(0u, wt);
-        xdma(n_steps > 1 ? 1u : 0u, xt + GT_TILE);
-        dma_fence();
-    } else {
-        fetch(0u, pf);
-        xload(0u, xr);
-        stage(pf);
-        xstore(xr, xt);
-        __syncthreads();
-        if (n_spans > 1) fetch(1u, pf);
-        decode(0u, wt);
-        xload(n_steps > 1 ? 1u : 0u, xr);
-        __syncthreads();
-    }
+    dma_span(0u, 0u);
+    xdma(0u, xt);
+    dma_fence();
+    if (GG::DBUF && n_spans > 1) dma_span(1u, 1u);
+    decode(0u, wt);
+    xdma(n_steps > 1 ? 1u : 0u, xt + GT_TILE);
+    dma_fence();
 
     // ---- main loop.  One K-step = [decode weight tile t+1 -> W[next]] + [MFMAs on X[cur], W[cur]] + [x tile t+1 -> X[next]] + one s_barrier.
     // decode(t + 1) and mma(t) are independent, so a wave may run them in either order: the waves that share a SIMD (w, w + 4, w + 8, ...: a
@@ -278,25 +251,29 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         uint8_t* const wcur = wt + P * GT_TILE;
         uint8_t* const xnxt = xt + (XR == 3 ? (step + 2u) % 3u : (uint32_t)(P ^ 1)) * GT_TILE;    // XR = 3: the buffer of step + 2 (read last at step - 1)
         uint8_t* const wnxt = wt + (P ^ 1) * GT_TILE;
-        if (DECODE && (step + 1) % GT_STEPS == 0) {
+        if (DECODE && (step + 1) % STEPS == 0) {
             // the next K-step opens a new span: every decode of the old one finished before the previous barrier
-            const uint32_t span = (step + 1) / GT_STEPS;
-            if constexpr (GG::DMA) {
+            const uint32_t span = (step + 1) / STEPS;
+            if constexpr (GG::DBUF) {
                 // span `span` landed in its buffer steps ago; the OTHER buffer (span - 1) is free: start filling it with span + 1
                 if (span + 1 < n_spans) dma_span(span + 1, (span + 1) & 1u);
             } else {
-                stage(pf);
-                __syncthreads();
-                if (span + 1 < n_spans) fetch(span + 1, pf);
+                dma_span(span, 0u);                     // one buffer: refill it now and wait for it (once per span)
+                dma_fence();
             }
         }
-        if constexpr (GG::DMA && XR == 3) {
-            // x tile of step + 2 (clamped at the end: a harmless re-read into a buffer nobody reads any more): two K-steps to land
-            if constexpr (DECODE) xdma(step + 2 < n_steps ? step + 2 : n_steps - 1, xnxt);
-        } else if constexpr (GG::DMA) {
-            // x tile of step + 1 straight into the other x buffer (free since the previous barrier); it has the whole K-step to land
-            if (step + 1 < n_steps) xdma(step + 1, xnxt);
+        if constexpr (DECODE) {
+            // x tile of step + 2 (XR = 3: two K-steps to land) or of step + 1; clamped at the end: a harmless re-read into a buffer nobody reads
+            if constexpr (XR == 3) xdma(step + 2 < n_steps ? step + 2 : n_steps - 1, xnxt);
+            else xdma(step + 1, xnxt);
         }
+#if GGQ_GT_ABLATE == 1             /* timing ablation (wrong results): no decode */
+        mma(xcur, wcur);
+        if constexpr (false)
+#elif GGQ_GT_ABLATE == 2           /* timing ablation (wrong results): no MFMAs */
+        if constexpr (DECODE) decode(step + 1, wnxt);
+        if constexpr (false)
+#endif
         if constexpr (!DECODE) {
             mma(xcur, wcur);
         } else if constexpr (PONG && GGQ_GT_PINGPONG) {
@@ -310,22 +287,14 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 #endif
             mma(xcur, wcur);
         }
-        if constexpr (GG::DMA && XR == 3) {
-            ring_fence();
-        } else if constexpr (GG::DMA) {
-            dma_fence();
-        } else {
-            // x tile of the next step: registers -> LDS; then the loads of the step after (clamped at the end: a harmless re-read)
-            xstore(xr, xnxt);
-            xload(step + 2 < n_steps ? step + 2 : n_steps - 1, xr);
-            __syncthreads();
-        }
+        if constexpr (XR == 3) ring_fence();
+        else dma_fence();
     };
     auto main_loop = [&](auto pong_tag) {
         using T0 = std::integral_constant<int, 0>;
         using T1 = std::integral_constant<int, 1>;
         uint32_t step = 0;
-        for (; step + 2 < n_steps; step += 2) {                     // n_steps is a multiple of 8
+        for (; step + 2 < n_steps; step += 2) {                     // n_steps is a multiple of 8 (cols % 256 == 0)
             kstep(step, T0{}, pong_tag, std::true_type{});
             kstep(step + 1, T1{}, pong_tag, std::true_type{});
         }
@@ -334,7 +303,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     };
     if ((wave >> 2) & 1) main_loop(std::true_type{});
     else main_loop(std::false_type{});
-    if constexpr (GG::DMA && XR == 3) dma_fence();           // nothing may still be landing in LDS when the epilogue reuses it
+    if constexpr (XR == 3) dma_fence();                      // nothing may still be landing in LDS when the epilogue reuses it
 
     // ---- epilogue: bias, cast, transpose through LDS (wave-private 4 KiB: 32 rows of x  x  64 columns), full-line stores.
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here

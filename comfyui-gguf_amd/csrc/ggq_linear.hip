@@ -19,7 +19,7 @@ typedef hipError_t (*lin_fn)(const void*, const void*, const void*, void*, uint3
 
 constexpr int MAX_DEVICES = 64;
 #ifndef GGQ_TILE_WM_DEFAULT
-#define GGQ_TILE_WM_DEFAULT 2
+#define GGQ_TILE_WM_DEFAULT 4
 #endif
 
 // compute units of the current device, asked once per device (the launch path runs per layer per step)
@@ -87,8 +87,8 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
 }
 
 // ---- the shared-tile kernel (ggq_gemm.hpp): 256 rows of x  x  256 output columns per workgroup, weights decoded once per workgroup.
-// WM = 2: 8 waves (128 x 64 outputs each, 2 waves per SIMD); WM = 4: 16 waves (64 x 64 each, 4 waves per SIMD).  GGQ_TILE_WM (environment, read
-// once: A/B runs) picks; EXPERIMENTS.md A2c has the comparison.
+// WM = 4 (shipped): 16 waves, 64 x 64 outputs each, 4 waves per SIMD; WM = 2: 8 waves, 128 x 64 each, 2 waves per SIMD -- 2-6 % slower
+// (profiles/r03_gemm_tile_16_waves_and_xring.json), compiled only into A/B builds (-DGGQ_TILE_WM_AB; GGQ_TILE_WM=2 in the environment then picks it).
 template <class F, int OUT, int WM>
 hipError_t launch_tile_wm(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
@@ -116,8 +116,11 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
         const char* e = getenv("GGQ_TILE_WM");
         return (e && *e == '4') ? 4 : ((e && *e == '2') ? 2 : GGQ_TILE_WM_DEFAULT);
     }();
-    if (wm == 4) return launch_tile_wm<F, OUT, 4>(packed, x, bias, y, m, rows, cols, s);
-    return launch_tile_wm<F, OUT, 2>(packed, x, bias, y, m, rows, cols, s);
+#ifdef GGQ_TILE_WM_AB      /* A/B builds carry both shapes; the shipped library only the default one */
+    if (wm != GGQ_TILE_WM_DEFAULT) return launch_tile_wm<F, OUT, (GGQ_TILE_WM_DEFAULT == 4 ? 2 : 4)>(packed, x, bias, y, m, rows, cols, s);
+#endif
+    (void)wm;
+    return launch_tile_wm<F, OUT, GGQ_TILE_WM_DEFAULT>(packed, x, bias, y, m, rows, cols, s);
 }
 
 // ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp): built, correct, 13 % SLOWER than the K-step-32 kernel (EXPERIMENTS.md
