@@ -48,9 +48,6 @@ constexpr int GT_WAVES = 8, GT_THREADS = GT_WAVES * 64;
 constexpr int GT_PITCH = GT_BK * 2;                      // bytes per tile row
 constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 KiB
 
-#ifndef GGQ_GT_SCHED
-#define GGQ_GT_SCHED 0      /* VALU instructions asked for behind every MFMA of a K-step (0 = leave the order to the compiler); A/B builds */
-#endif
 #ifndef GGQ_GT_CROSS
 #define GGQ_GT_CROSS 0x100  /* what may be scheduled ACROSS the line between the two halves of a K-step: LDS reads (so the second half's operands
                                are already on their way while the first half runs); 0 = nothing; A/B builds */

@@ -9,6 +9,12 @@ weights are asked for (it repeats every denoising step) and, on a call for weigh
 ``depth - 1`` weights it expects next in ONE launch per format (include/ggq.h ``ggq_dequant_batch``: descriptors by value, nothing to
 build or keep); the following calls are handed their tensors without a launch.
 
+Measured (round 3, profiles/r03_flux_forward_emulation_fused_and_lookahead.json; bench.py ``workloads.per_layer``): with nothing between
+the unpacks it helps (304 launches -> 76: 6151 -> 6326 GB/s eager), but inside a forward it LOSES -- an emulated FLUX.1-dev step is
++0.8 ms at depth 2 and +3.9 ms at depth 4 -- because a weight that was unpacked three layers early has left the Infinity Cache by the time
+its GEMM reads it, and cache residency is what makes the default per-layer path nearly free (DESIGN.md section 4a, sc1 stores).  It stays
+in the tree as a documented negative result and for callers that unpack without a GEMM in between.
+
 What it changes, and why it is opt-in (``install(..., lookahead=K)`` / ``GGQ_LOOKAHEAD=K``):
   * values: nothing -- the same kernels, the same bits; every result is a FRESH tensor from torch's allocator that nobody else holds
     (so the LoRA branch of ``get_weight``, which patches the dequantized weight in place, ops.py:183-190, works unchanged);
