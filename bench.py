@@ -178,6 +178,44 @@ def cpu_baseline_reference(pkg, plan, qtypes, budget_s):
             "parity_vs_gpu": "bit-exact" if parity else "MISMATCH"}
 
 
+def reference_gpu_leg(pkg, plan, qtypes, device):
+    """The reference's own eager torch ops (dequant.py:30-44, verbatim) on THIS GPU, over the same device-resident packed bytes the HIP
+    path just read: the first (3072x3072, 3072x12288) pair of the pool.  What the reference delivers on an MI355X without this
+    library -- a baseline beside `cpu_baseline`, and one more checker (outputs compared on the device, bit for bit)."""
+    from oracle import reference
+    if not reference.available():
+        return None
+    ref = reference.load_reference_dequant()
+    n_sample = min(2, len(plan.outputs))
+    packed = [plan._keep[i] for i in range(n_sample)]
+    shapes = [tuple(plan.outputs[i].shape) for i in range(n_sample)]
+    qs = [qtypes[i] for i in range(n_sample)]
+    import numpy as np
+    nbytes = sum(pkg.qtypes.algorithmic_bytes(q, int(np.prod(sh))) for q, sh in zip(qs, shapes))
+    parity = all(torch.equal(ref.dequantize(p, q, sh).view(torch.int16), plan.outputs[i].view(torch.int16)) for i, (p, q, sh) in enumerate(zip(packed, qs, shapes)))
+
+    def one_pass():
+        for p, q, sh in zip(packed, qs, shapes):
+            ref.dequantize(p, q, sh)
+
+    for _ in range(3):
+        one_pass()
+    torch.cuda.synchronize(device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    a.record()
+    for _ in range(reps):
+        one_pass()
+    b.record()
+    torch.cuda.synchronize(device)
+    ms = a.elapsed_time(b) / reps
+    torch.cuda.empty_cache()
+    return {"value": round(nbytes / (ms * 1e-3) / 1e9, 1), "unit": "GB/s", "ms_per_pass": round(ms, 4),
+            "sample": (f"reference dequant.py:30 dequantize() verbatim ({reference.source()} copy), eager torch-ROCm ops on cuda: "
+                       f"{' + '.join(f'{q.name} {sh[0]}x{sh[1]}' for q, sh in zip(qs, shapes))} (the pool's first pair, device-resident), {reps} passes after 3 warm-up, HIP events"),
+            "parity_vs_hip_path": "bit-exact" if parity else "MISMATCH"}
+
+
 def cpu_baseline_port(pkg, plan, qtype, budget_s):
     """kind 'port': the oracle's throughput leg (oracle/ggq_oracle_simd.c: the same op sequence with AVX2+F16C and OpenMP) on the
     first tensors of the pool -- the fastest CPU implementation of this path the repo has, reported BESIDE the reference's own
@@ -511,6 +549,41 @@ def run_per_layer(pkg, args, device, fence):
     del dense
     torch.cuda.empty_cache()
 
+    # the reference's OWN path on this GPU: its eager torch ops (dequant.py:15-44, executed verbatim from /root/reference or the staged
+    # oracle/_ref copy) over the same 304 device tensors -- what a user of the reference gets on an MI355X today.  A baseline and a
+    # checker (every tensor compared with the HIP path's result, bit for bit), never part of a timed region of the product.
+    ref_gpu = None
+    from oracle import reference
+    if reference.available():
+        ref = reference.load_reference_dequant()
+        plain = []
+        for t, (_, q, shape) in zip(tensors, manifest):
+            u = t.as_subclass(torch.Tensor)
+            u = u.view(u.shape)                        # a fresh tensor object to hang the reference's attributes on (ops.py:44-60)
+            u.tensor_type, u.tensor_shape = q, torch.Size(shape)
+            plain.append(u)
+        bad = [name for (name, _, _), u, t in zip(manifest, plain, tensors)
+               if not torch.equal(ref.dequantize_tensor(u, dtype).view(torch.int16), dq(t, dtype).view(torch.int16))]
+
+        def ref_pass():
+            for u in plain:
+                ref.dequantize_tensor(u, dtype)
+
+        def ref_step():
+            for u, x in zip(plain, layer_x):
+                lin(x, ref.dequantize_tensor(u, dtype))
+
+        (r_ms, _), r_regs = median(ref_pass, 1, warm=1)
+        (rs_ms, _), rs_regs = median(ref_step, 1, warm=1)
+        ref_gpu = {"what": f"reference dequantize_tensor() verbatim ({reference.source()} copy), eager torch-ROCm ops on the same device tensors, bf16 result",
+                   "standalone_ms_per_pass": round(r_ms, 3), "standalone_GBps": round(nbytes / (r_ms * 1e-3) / 1e9, 1), "standalone_regions_ms": r_regs,
+                   "in_context_ms_per_step": round(rs_ms, 3), "in_context_dequant_cost_ms_per_step": round(rs_ms - d_ms, 3), "in_context_regions_ms": rs_regs,
+                   "hip_path_speedup_standalone_eager": round(r_ms / e_ms, 1),
+                   "hip_path_step_speedup_in_context": round(rs_ms / ctx["shipped_sc1"]["ms_per_step"], 2),
+                   "parity_vs_hip_path": f"bit-exact ({len(plain)} tensors)" if not bad else f"MISMATCH {bad[:3]}"}
+        del plain
+        torch.cuda.empty_cache()
+
     g = standalone["shipped_sc1"]
     return {
         "metric": "dequant GB/s, one dequantize_tensor() launch per layer (packed in -> bf16 out), (in+out) bytes / time",
@@ -526,6 +599,7 @@ def run_per_layer(pkg, args, device, fence):
                                              "launches": ahead_stats["launches"], "hits": ahead_stats["hits"],
                                              "note": "opt-in install(lookahead=4): the same tensors, one ggq_dequant_batch launch per 4 layers"},
                    "in_context": ctx,
+                   "reference_on_this_gpu": ref_gpu,
                    "parity_vs_oracle": parity},
         "roofline": {"bound": "hbm", "achieved": g["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g["GBps"] / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "ggq::dequant_one<Fmt*, ...> (one launch per tensor; team shape picked per tensor size; sc1 stores)",
@@ -719,6 +793,10 @@ def main():
             result["cpu_baseline"], port = cpu_baselines(pkg, plan_head, [head_q] * len(plan_head.outputs), args.cpu_seconds)
             if port is not None:
                 result["cpu_baseline_port"] = port
+            rg = reference_gpu_leg(pkg, plan_head, [head_q] * len(plan_head.outputs), device)
+            if rg is not None:
+                rg["hip_path_speedup"] = round(result["roofline"]["achieved"] / rg["value"], 1)
+                result["reference_on_this_gpu"] = rg
     plan_head.close()
     del plan_head, plan
     torch.cuda.empty_cache()
