@@ -452,6 +452,8 @@ def run_per_layer(pkg, args, device, fence):
         stores win by a wide margin over non-temporal ones, because the GEMM finds the weight in the Infinity Cache; that is why they ship.
     Three timed regions each, median reported, HIP events on the launch stream."""
     manifest = pkg.manifests.flux_dev(args.mix)
+    if args.limit_tensors:
+        manifest = manifest[:args.limit_tensors]               # smoke runs / tests
     tensors = []
     for i, (_, q, shape) in enumerate(manifest):
         n_blocks = pkg.synth.n_blocks_for(q, shape[0] * shape[1])
@@ -639,7 +641,7 @@ def main():
     ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
-    ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf: only the first N tensors (smoke runs)")
+    ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf / per-layer: only the first N tensors (smoke runs, tests)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

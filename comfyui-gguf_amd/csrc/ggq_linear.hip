@@ -39,13 +39,19 @@ template <class F, int OUT, int M>
 hipError_t launch(const void* packed, const void* x, const void* bias, void* y, uint32_t rows, uint32_t cols, hipStream_t s)
 {
     const uint32_t x_bytes = ((uint32_t)M * cols * XBytes<OUT>::V + 15u) & ~15u;
-    const uint32_t lds = x_bytes + LIN_WAVES * LIN_SLICE;
+    const uint32_t slice = lin_slice_bytes(cols / F::BS * F::TS);
+    const uint32_t lds = x_bytes + LIN_WAVES * slice;
     // persistent grid: enough waves to keep every CU's slots full, never more workgroups than rows need
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint32_t cus = compute_units(dev);
     const uint32_t need = (rows + LIN_WAVES - 1) / LIN_WAVES;
-    const uint32_t per_cu = lds <= 20 * 1024 ? 8u : (lds <= 40 * 1024 ? 4u : (lds <= 80 * 1024 ? 2u : 1u));
+    uint32_t per_cu = (152u * 1024u) / lds;             // workgroups whose LDS fits one CU (160 KiB, some left to the allocator's granularity) ...
+    per_cu = per_cu > 8u ? 8u : (per_cu < 1u ? 1u : per_cu);   // ... up to the 32 wave slots of a CU at <= 64 VGPRs
+    if (const char* e = std::getenv("GGQ_LIN_PER_CU")) {       // A/B runs
+        const int v = std::atoi(e);
+        if (v >= 1 && (uint32_t)v < per_cu) per_cu = (uint32_t)v;
+    }
     const uint32_t grid = need < cus * per_cu ? need : cus * per_cu;
     if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
         static std::atomic<uint64_t> raised{0};
@@ -57,7 +63,7 @@ hipError_t launch(const void* packed, const void* x, const void* bias, void* y, 
         }
     }
     hipLaunchKernelGGL((linear_small<F, OUT, M>), dim3(grid), dim3(LIN_WAVES * 64), lds, s, static_cast<const uint8_t*>(packed),
-                       static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), rows, cols);
+                       static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), rows, cols, slice);
     return hipGetLastError();
 }
 
@@ -218,7 +224,7 @@ extern "C" int ggq_linear_small(int qtype, const void* packed, uint32_t rows, ui
     if (cols == 0 || cols % (uint32_t)e->block_size != 0) return GGQ_ERR_ARG;
     const uint64_t row_bytes = (uint64_t)cols / (uint32_t)e->block_size * (uint32_t)e->type_size;
     const uint64_t x_bytes = (uint64_t)m * cols * (dtype == GGQ_F32 ? 4 : 2);
-    if (row_bytes + 15 > (uint64_t)LIN_SLICE || x_bytes + (uint64_t)LIN_WAVES * LIN_SLICE > 150 * 1024) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
+    if (row_bytes + 15 > (uint64_t)LIN_SLICE || x_bytes + (uint64_t)LIN_WAVES * lin_slice_bytes((uint32_t)row_bytes) > 150 * 1024) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
     if (!packed || !x || !y) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
     const hipError_t err = e->fn[dtype][m - 1](packed, x, bias, y, rows, cols, static_cast<hipStream_t>(hip_stream));

@@ -73,20 +73,24 @@ GGQ_DEV void weights8(const Fields& f, uint32_t (&w)[4])
 }
 
 constexpr int LIN_NU_MAX = 6;                    // 16-byte load units per lane per row: rows of up to 6128 packed bytes
-constexpr int LIN_SLICE = LIN_NU_MAX * 64 * 16;  // LDS bytes per wave for one row (+ up to 15 bytes of leading misalignment)
+constexpr int LIN_SLICE = LIN_NU_MAX * 64 * 16;  // the LARGEST LDS slice a wave can need for one row (+ up to 15 bytes of leading misalignment)
 constexpr int LIN_WAVES = 4;
+
+// LDS bytes per wave for rows of `row_bytes` packed bytes: whole 64-lane x 16-byte load units (a row may start up to 15 bytes into its first
+// unit).  Sized to the row, not to LIN_SLICE: a 3072-column Q4_K row takes 2 KiB, so eight workgroups fit a CU instead of four.
+constexpr uint32_t lin_slice_bytes(uint32_t row_bytes) { return (row_bytes + 15u + 1023u) & ~1023u; }
 
 template <class F, int OUT, int M>
 __global__ __launch_bounds__(LIN_WAVES * 64) void linear_small(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                                const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
-                                                               uint32_t rows, uint32_t cols)
+                                                               uint32_t rows, uint32_t cols, uint32_t slice_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const gcptr packed = (gcptr)packed_;
     constexpr int XB = XBytes<OUT>::V;
     uint8_t* xs = lds;                                                    // m x cols values of x
     const uint32_t x_bytes = (uint32_t)M * cols * XB;
-    uint8_t* slice = lds + ((x_bytes + 15u) & ~15u) + (threadIdx.x >> 6) * LIN_SLICE;
+    uint8_t* slice = lds + ((x_bytes + 15u) & ~15u) + (threadIdx.x >> 6) * slice_bytes;
     for (uint32_t o = threadIdx.x * 16u; o < x_bytes; o += LIN_WAVES * 64 * 16)
         *reinterpret_cast<u32x4*>(xs + o) = *reinterpret_cast<const u32x4*>(x_ + o);
     __syncthreads();

@@ -105,7 +105,9 @@ def linear_small(x, weight, bias=None, dequant_dtype=None, weight_to=None):
     if not 1 <= m <= MAX_ROWS:
         raise GGQUnsupported(f"fused linear takes 1..{MAX_ROWS} input rows, got {m}")
     _, block_size, type_size = _HIP_TABLE[_qtype_key(qid)]
-    if cols % block_size or cols // block_size * type_size + 15 > _LIN_SLICE or m * cols * x.element_size() + _LIN_WAVES * _LIN_SLICE > 150 * 1024:
+    row_bytes = cols // block_size * type_size
+    slice_bytes = (row_bytes + 15 + 1023) & ~1023          # csrc/ggq_linear.hpp lin_slice_bytes(): whole 64-lane x 16-byte load units per wave
+    if cols % block_size or row_bytes + 15 > _LIN_SLICE or m * cols * x.element_size() + _LIN_WAVES * slice_bytes > 150 * 1024:
         raise GGQUnsupported("fused linear: a row's packed bytes (or x) exceed the kernel's LDS staging")     # what ggq_linear_small answers GGQ_ERR_ARG to
     if _small_call is None:
         _bind()

@@ -384,3 +384,28 @@ def test_cpu_route_for_load_time_tensors(mods, pkg, dev, monkeypatch):
     with H.Installed(pkg, mods):                                     # option off: everything stays on the CPU
         assert H.same_bits(rd.dequantize_tensor(big, torch.float16), want[(id(big), torch.float16, None)])
     assert counter.n == 4
+
+
+@pytest.mark.timeout(600)
+def test_bench_reports_the_reference_on_this_gpu():
+    """bench.py --workload per-layer (first 12 FLUX tensors): the sub-line carries the reference's own eager torch path on the same device
+    tensors -- standalone and in context -- and every one of its results was compared with the HIP path's, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, "bench.py", "--workload", "per-layer", "--limit-tensors", "12", "--steps", "20", "--regions", "3"],
+                          cwd=root, capture_output=True, text=True, timeout=540)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert cfg["launches_per_pass"] == 12 and cfg["parity_vs_oracle"] == "bit-exact (12 tensors)"
+    ref = cfg["reference_on_this_gpu"]
+    assert ref is not None and ref["parity_vs_hip_path"] == "bit-exact (12 tensors)"
+    assert ref["standalone_ms_per_pass"] > 0 and ref["in_context_ms_per_step"] > 0
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    for policy in ("shipped_sc1", "streaming_nt"):
+        assert cfg["standalone_gpu_bound"][policy]["GBps"] > 0 and len(cfg["in_context"][policy]["regions_ms"]) == 3

@@ -45,11 +45,44 @@ def main():
                     b.record()
                     torch.cuda.synchronize()
                     return a.elapsed_time(b) * 1e3 / len(layers)
+                def graphed(fn):
+                    # GPU time without the host's issue rate: the same calls replayed from a captured HIP graph
+                    side = torch.cuda.Stream()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        keep = [fn(w) for w in layers]
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g, stream=side):
+                            keep = [fn(w) for w in layers]
+                    g.replay()
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(5):
+                        g.replay()
+                    b.record()
+                    torch.cuda.synchronize()
+                    del keep
+                    return a.elapsed_time(b) * 1e3 / (5 * len(layers))
                 fused = timed(lambda w: pkg.fused.linear_small(x, w))
+                fused_gpu = graphed(lambda w: pkg.fused.linear_small(x, w))
+                dense = [pkg.dequant.dequantize_tensor(w, torch.bfloat16) for w in layers[:12]]
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(3):
+                    for wd in dense:
+                        torch.nn.functional.linear(x, wd)
+                b.record()
+                torch.cuda.synchronize()
+                dense_us = a.elapsed_time(b) * 1e3 / (3 * len(dense))
+                del dense
                 two = timed(lambda w: torch.nn.functional.linear(x, pkg.dequant.dequantize_tensor(w, torch.bfloat16)))
                 packed = rows * cols // bs * ts
                 out[f"{qname} {rows}x{cols} m={m}"] = {"fused_us": round(fused, 2), "dequant_plus_linear_us": round(two, 2), "speedup": round(two / fused, 2),
-                                                        "fused_packed_read_GBps": round(packed / fused / 1e3, 1)}
+                                                        "fused_packed_read_GBps": round(packed / fused / 1e3, 1),
+                                                        "fused_graph_replay_us": round(fused_gpu, 2), "fused_graph_replay_packed_GBps": round(packed / fused_gpu / 1e3, 1),
+                                                        "linear_on_dense_resident_us": round(dense_us, 2)}
             del layers
             torch.cuda.empty_cache()
     print(json.dumps(out, indent=1))
