@@ -27,6 +27,8 @@ from ggq_pkg import load_package  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=4608)        # 4096 image + 512 text tokens at 1024x1024
+    ap.add_argument("--model", default="flux", choices=["flux", "sd35", "t5"], help="which weight set's linears: FLUX.1-dev (configs[3]); SD3.5-large MMDiT or the "
+                    "T5-xxl encoder (the two halves of configs[4]; T5's token_embd table is an embedding lookup, not a linear, and is left out)")
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--mix", default="Q4_K_M")
@@ -43,7 +45,9 @@ def main():
     pkg.ops.GGMLLinear.fuse_mfma_max_m = args.fused_mfma
     dev = torch.device("cuda:0")
     dtype = getattr(torch, args.dtype)
-    manifest = pkg.manifests.flux_dev(args.mix)
+    manifest = {"flux": pkg.manifests.flux_dev, "sd35": pkg.manifests.sd35_large, "t5": pkg.manifests.t5_xxl_encoder}[args.model](args.mix)
+    manifest = [e for e in manifest if e[0] != "token_embd.weight"]
+    label = {"flux": "FLUX.1-dev", "sd35": "SD3.5-large", "t5": "T5-xxl encoder"}[args.model]
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     layers, inputs = [], {}
@@ -55,7 +59,7 @@ def main():
             vals = (torch.rand(n_blocks, device=dev, generator=g) * 1e-3 + 1e-4).to(torch.float16)
             data[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
         w = pkg.ops.GGMLTensor(data.reshape(-1).cpu() if args.lowvram else data.reshape(-1), tensor_type=q, tensor_shape=(rows, cols))
-        m = 1 if ("mod" in name) else args.tokens
+        m = 1 if ("mod" in name or "adaLN" in name) else args.tokens      # modulation layers act on the conditioning vector: one row
         if (m, cols) not in inputs:
             inputs[(m, cols)] = torch.randn(m, cols, device=dev, dtype=dtype) * 0.05
         layers.append((pkg.ops.GGMLLinear(w), inputs[(m, cols)]))
@@ -123,7 +127,7 @@ def main():
     flops = sum(2.0 * x.shape[0] * lin.weight.shape[0] * lin.weight.shape[1] for lin, x in layers)
     n_el = sum(lin.weight.shape[0] * lin.weight.shape[1] for lin, _ in layers)
     print(json.dumps({
-        "workload": f"FLUX.1-dev linears ({len(layers)} layers, {args.mix}, {n_el / 1e9:.2f} G weights), {args.tokens} tokens, {args.dtype}",
+        "workload": f"{label} linears ({len(layers)} layers, {args.mix}, {n_el / 1e9:.2f} G weights), {args.tokens} tokens, {args.dtype}",
         "ms_per_step_dequant_on_the_fly": round(q_med, 2), "ms_per_step_dense_resident": round(d_med, 2),
         "dequant_cost_ms_per_step": round(q_med - d_med, 2), "dequant_share_of_step_pct": round(100 * (q_med - d_med) / q_med, 1),
         "best_ms": {"on_the_fly": round(q_min, 2), "dense": round(d_min, 2)},
