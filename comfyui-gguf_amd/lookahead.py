@@ -26,7 +26,6 @@ What it changes, and why it is opt-in (``install(..., lookahead=K)`` / ``GGQ_LOO
     ops.py:209) are never predicted -- that mode is what overlap.py is for.  Tracing under torch.compile, HIP-graph capture and calls
     from another thread than the first one take the plain path.
 """
-import ctypes
 import threading
 import weakref
 
