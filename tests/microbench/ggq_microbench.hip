@@ -628,20 +628,44 @@ static void ab_add(AB& ab, const char* name, Pool& P, int dyn_lds = 0, uint32_t 
 
 // Round 2: LAYER-SIZED launches -- one dequant_one per tensor, tensor after tensor, as ComfyUI issues them (ops.py:177) -- where a launch
 // is 1-5 dispatch rounds of workgroups and ramp / tail / drain are a third of the time.  One "launch" of the AB = one pass over the pool.
-template <class F, int G, int WAVES, bool COOP, bool NTL = true>
+template <class F, int G, int WAVES, bool COOP, bool NTL = true, int OUT = ggq::OUT_F16, bool NTS = true>
 static void ab_add_layer(AB& ab, const char* name, Pool& P, uint32_t xrun, int dyn_lds = 0)
 {
     std::vector<ggq::Desc> d = P.descs;
     char buf[160];
-    snprintf(buf, sizeof buf, "%s layer %s G=%d waves=%d ntl=%d xrun=%u dynlds=%dK", name, COOP ? "coop" : "solo", G, WAVES, (int)NTL, xrun, dyn_lds / 1024);
+    snprintf(buf, sizeof buf, "%s layer %s G=%d waves=%d ntl=%d xrun=%u %s %s", name, COOP ? "coop" : "solo", G, WAVES, (int)NTL, xrun, OUT == ggq::OUT_BF16 ? "bf16" : "f16",
+             NTS ? "nt" : "sc1");
     ab.v.push_back(ABVariant{buf, [=] {
                                  for (const ggq::Desc& t : d) {
                                      const uint64_t groups = (t.n_blocks + G - 1) / G;
-                                     hipLaunchKernelGGL((ggq::lab::dequant_one<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP>),
+                                     hipLaunchKernelGGL((ggq::lab::dequant_one<F, G, OUT, NTL, NTS, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP>),
                                                         dim3((uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES)), dim3(WAVES * 64), dyn_lds, nullptr, t, groups, xrun);
                                  }
                              },
-                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, true, WAVES, 0, false, -1, 1, COOP>()});
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, check_variant<F, G, NTL, NTS, WAVES, 0, false, -1, 1, COOP>()});   // parity of the shape (fp16 leg)
+}
+
+// Round 3: the same sweep for what the node really launches -- bf16 result, write-through (sc1) stores (Next #2 candidate (c))
+template <class F, int GB>
+static void ab_layer_bf16(const char* name, int qi, std::initializer_list<uint64_t> sizes)
+{
+    constexpr int B = ggq::OUT_BF16;
+    for (uint64_t el : sizes) {
+        const int n_t = (int)std::max<uint64_t>(6, std::min<uint64_t>(48, (600ull << 20) / (el * 2)));
+        Pool Q = make_pool(QTS[qi], n_t, el);
+        printf("LAYER-BF16 %s: %d tensors of %llu elements (%.1f M), one launch each, bf16 result, sc1 stores\n", name, n_t, (unsigned long long)el, el / 1e6);
+        AB ab;
+        ab_add_layer<F, 2 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 4096 (whole-model coop shape)
+        ab_add_layer<F, 2 * GB, 4, true, true, B, false>(ab, name, Q, 5);
+        ab_add_layer<F, 4 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 8192 (TuneMid)
+        ab_add_layer<F, 4 * GB, 2, true, true, B, false>(ab, name, Q, 0);      // 2 waves x 8192
+        ab_add_layer<F, 8 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 16384
+        ab_add_layer<F, GB, 4, false, true, B, false>(ab, name, Q, 0);         // one-wave teams x 2048, 4 per workgroup
+        ab_add_layer<F, GB, 1, false, true, B, false>(ab, name, Q, 0);         // one-wave teams x 2048
+        ab_add_layer<F, 4 * GB, 4, true, true, B, true>(ab, name, Q, 0);       // TuneMid with non-temporal stores (reference point)
+        ab.run(12, 4);
+        free_pool(Q);
+    }
 }
 
 template <class F, int GB /* blocks per 2048 elements */>
@@ -1233,6 +1257,10 @@ int main(int argc, char** argv)
         ab_layer<ggq::FmtQ6_K, 8>("Q6_K", 9, {3072ull * 3072, 4096ull * 4096, 9216ull * 3072});
         ab_layer<ggq::FmtQ2_K, 8>("Q2_K", 5, {3072ull * 3072, 4096ull * 4096});
         ab_layer<ggq::FmtIQ4_XS, 8>("IQ4_XS", 11, {3072ull * 3072, 4096ull * 4096});
+    }
+    if (what == "ablayer3") {     // round 3: layer-sized launches with bf16 result and write-through stores: FLUX, T5 and SD3.5 layer sizes
+        ab_layer_bf16<ggq::FmtQ4_K, 8>("Q4_K", 7, {3072ull * 3072, 4096ull * 4096, 9216ull * 3072, 12288ull * 3072, 10240ull * 4096, 3072ull * 15360, 18432ull * 3072, 21504ull * 3072});
+        ab_layer_bf16<ggq::FmtQ5_0, 64>("Q5_0", 2, {2432ull * 2432, 7296ull * 2432, 9728ull * 2432, 14592ull * 2432});
     }
     if (what == "abq3k") ab_q3k_line_exact();
     if (what == "ablds") {          // round 3: LDS-staged vs no-LDS ("direct", zero bank conflicts by construction) for the 2-byte-aligned legacy formats
