@@ -148,19 +148,38 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="ggq_build_") as tmp:
         out = os.path.join(tmp, "libggq_hip.so")
-        cmd = [hipcc_path()] + HIPCC_FLAGS + [f'-DGGQ_BUILD_ID="{source_id()}"', "-save-temps=obj", "-o", out] + SOURCES
-        proc = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
-        if verbose or proc.returncode:
-            print(" ".join(cmd))
-            print(proc.stdout + proc.stderr)
-        if proc.returncode:
-            raise GGQNativeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-        asm = [f for f in os.listdir(tmp) if f.endswith(".s") and "amdgcn" in f]
-        if not asm:
+        # one hipcc -c per translation unit, all at once (the four take 20-40 s each), then one link
+        compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+        jobs = []
+        for src in SOURCES:
+            stem = os.path.splitext(os.path.basename(src))[0]
+            d = os.path.join(tmp, stem)
+            os.makedirs(d)
+            cmd = [hipcc_path()] + compile_flags + [f'-DGGQ_BUILD_ID="{source_id()}"', "-save-temps=obj", "-c", "-o", os.path.join(d, stem + ".o"), src]
+            jobs.append((cmd, d, subprocess.Popen(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        failed = None
+        for cmd, d, proc in jobs:
+            so, se = proc.communicate()
+            if verbose or proc.returncode:
+                print(" ".join(cmd))
+                print(so + se)
+            if proc.returncode and failed is None:
+                failed = (proc.returncode, se)
+        if failed:
+            raise GGQNativeError(f"hipcc failed ({failed[0]}):\n{failed[1][-4000:]}")
+        asm = [os.path.join(d, f) for _, d, _ in jobs for f in os.listdir(d) if f.endswith(".s") and "amdgcn" in f]
+        if len(asm) < len(SOURCES):
             raise GGQNativeError("build produced no gfx950 assembly to check for FMA contraction")
         for f in asm:
-            with open(os.path.join(tmp, f)) as fh:
+            with open(f) as fh:
                 check_no_fma(fh.read())
+        link = [hipcc_path()] + HIPCC_FLAGS + ["-o", out] + [os.path.join(d, os.path.basename(d) + ".o") for _, d, _ in jobs]
+        proc = subprocess.run(link, cwd=tmp, capture_output=True, text=True)
+        if verbose or proc.returncode:
+            print(" ".join(link))
+            print(proc.stdout + proc.stderr)
+        if proc.returncode:
+            raise GGQNativeError(f"hipcc link failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
         shutil.copyfile(out, LIB_PATH + ".tmp")
         os.replace(LIB_PATH + ".tmp", LIB_PATH)
     _lib = None
