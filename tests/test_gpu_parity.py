@@ -121,6 +121,29 @@ def test_dequant_dtype_modes_golden(pkg, golden_dir, name, compute):
 
 
 @pytest.mark.parametrize("name", ALL)
+def test_every_fp16_bit_pattern_of_every_scale_field(pkg, name):
+    """EXHAUSTIVE over the scale operands: all 65 536 bit patterns of each fp16 scale field of the format (both zeros, every subnormal, every
+    normal, both infinities, every NaN payload), each against a block of random quants and randomly signed other fields -- the stock fp16
+    arithmetic and the two other arithmetic modes, bit-exact against the oracle (NaN payloads canonicalised)."""
+    q = pkg.qtypes.Q[name]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    pats = np.arange(65536, dtype=np.uint32)
+    for k, off in enumerate(pkg.qtypes.SCALE_FIELDS[q]):
+        blocks = pkg.synth.make_blocks(q, 65536, seed=4242 + k, mode="signed")
+        blocks[:, off] = (pats & 0xFF).astype(np.uint8)
+        blocks[:, off + 1] = (pats >> 8).astype(np.uint8)
+        t = _carrier(pkg, blocks, q)
+        for compute in ("f16", "bf16", "f32"):
+            want = oracle.dequant_tensor(q, blocks, compute, compute)
+            got = pkg.dequant.dequantize_tensor(t, _TORCH[compute], dequant_dtype=None if compute == "f16" else _TORCH[compute])
+            assert tuple(got.shape) == (65536, bs)
+            g, w = _canon(_raw(got), compute), _canon(want, compute)
+            if not np.array_equal(g, w):
+                bad = np.flatnonzero(g != w)
+                raise AssertionError(f"{name} field@{off} {compute}: {bad.size} elements differ, first at block {bad[0] // bs} (scale bits {bad[0] // bs:#06x})")
+
+
+@pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("mode", ["signed", "adversarial"])
 def test_dequant_tensor_all_dtype_combinations(pkg, name, mode):
     """dequantize_tensor(tensor, dtype, dequant_dtype) for every (dequant_dtype, dtype) pair the nodes can

@@ -409,3 +409,28 @@ def test_bench_reports_the_reference_on_this_gpu():
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     for policy in ("shipped_sc1", "streaming_nt"):
         assert cfg["standalone_gpu_bound"][policy]["GBps"] > 0 and len(cfg["in_context"][policy]["regions_ms"]) == 3
+
+
+@pytest.mark.parametrize("qname", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_NL", "IQ4_XS"])
+def test_every_fp16_scale_bit_pattern_against_the_reference_on_the_gpu(mods, pkg, dev, qname):
+    """All 65 536 bit patterns of every fp16 scale field, random quants: the reference's own eager torch ops on the GPU == the HIP path, fp16
+    and bf16 results."""
+    rd = mods["dequant"]
+    q = pkg.qtypes.Q[qname]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    pats = np.arange(65536, dtype=np.uint32)
+    for k, off in enumerate(pkg.qtypes.SCALE_FIELDS[q]):
+        blocks = pkg.synth.make_blocks(q, 65536, seed=977 + k, mode="signed")
+        blocks[:, off] = (pats & 0xFF).astype(np.uint8)
+        blocks[:, off + 1] = (pats >> 8).astype(np.uint8)
+        data = torch.from_numpy(blocks.reshape(-1).copy()).to(dev)
+        for dtype in (torch.float16, torch.bfloat16):
+            want = rd.dequantize(data, q, (65536, bs)).to(dtype)                       # dequant.py:30 + the .to(dtype) of dequant.py:23
+            got = pkg.dequant.dequantize(data, q, (65536, bs)).to(dtype) if dtype is torch.float16 else \
+                pkg.dequant.dequantize_tensor(pkg.ops.GGMLTensor(data, tensor_type=q, tensor_shape=(65536, bs)), dtype)
+            assert H.same_bits(got, want), (qname, off, dtype)                       # NaN payloads canonicalised (ref_harness.bits)
+            if dtype is torch.float16 and qname not in ("Q2_K", "Q4_K", "Q5_K"):
+                # ... and for the fp16 result even the NaN payloads are the reference's (same hardware ops in the same operand order) -- observed, not
+                # contracted: the three formats that subtract `dmin * m` fold the subtraction into an add with a negated operand, which flips the SIGN
+                # of a NaN; and torch's .to(bfloat16) writes the canonical 0x7FC0 for every NaN where the hardware converter keeps sign + payload
+                assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (qname, off, "raw fp16 bits incl. NaN payloads")
