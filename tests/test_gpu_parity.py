@@ -143,6 +143,38 @@ def test_every_fp16_bit_pattern_of_every_scale_field(pkg, name):
                 raise AssertionError(f"{name} field@{off} {compute}: {bad.size} elements differ, first at block {bad[0] // bs} (scale bits {bad[0] // bs:#06x})")
 
 
+@pytest.mark.parametrize("name", ["Q8_0", "Q4_0", "Q5_0", "IQ4_NL"])
+def test_every_scale_times_every_quant_value(pkg, name):
+    """The formats of the shape `d * value(q)`: EVERY (fp16 scale bit pattern, quant value) pair -- 65 536 x 256 for Q8_0 (the format the north
+    star wants bit-exact), x 16 / 32 / 16 for Q4_0 / Q5_0 / IQ4_NL, each value in both nibble positions -- in the three arithmetic modes."""
+    q = pkg.qtypes.Q[name]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    reps = 8 if name == "Q8_0" else 1
+    blocks = np.zeros((65536 * reps, ts), dtype=np.uint8)
+    pats = np.repeat(np.arange(65536, dtype=np.uint32), reps)
+    blocks[:, 0] = (pats & 0xFF).astype(np.uint8)
+    blocks[:, 1] = (pats >> 8).astype(np.uint8)
+    if name == "Q8_0":
+        blocks[:, 2:] = (np.arange(32, dtype=np.uint32)[None, :] + 32 * (np.arange(65536 * reps, dtype=np.uint32) % 8)[:, None]).astype(np.uint8)
+    else:
+        nib = (np.arange(16, dtype=np.uint32) * 0x11).astype(np.uint8)            # byte k = 0xkk: element k AND element 16 + k take the value k
+        blocks[:, ts - 16:] = nib[None, :]
+        if name == "Q5_0":
+            blocks[:, 2:6] = np.array([0x00, 0x00, 0xFF, 0xFF], dtype=np.uint8)     # qh: bit e set for e >= 16 -> q = 0..15 then 16..31
+    t = _carrier(pkg, blocks, q)
+    for compute in ("f16", "bf16", "f32"):
+        want = oracle.dequant_tensor(q, blocks, compute, compute)
+        got = pkg.dequant.dequantize_tensor(t, _TORCH[compute], dequant_dtype=None if compute == "f16" else _TORCH[compute])
+        g, w = _canon(_raw(got), compute), _canon(want, compute)
+        if not np.array_equal(g, w):
+            bad = np.flatnonzero(g != w)
+            raise AssertionError(f"{name} {compute}: {bad.size} of {g.size} (scale, quant) pairs differ, first: scale bits {pats[bad[0] // bs]:#06x}, element {bad[0] % bs}")
+    if name == "Q5_0":                                                             # the other half of the (nibble position, high bit) table
+        blocks[:, 2:6] = np.array([0xFF, 0xFF, 0x00, 0x00], dtype=np.uint8)
+        got = pkg.dequant.dequantize_tensor(_carrier(pkg, blocks, q), torch.float16)
+        assert np.array_equal(oracle.canon_nan_f16(_bits16(got)), oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)))
+
+
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("mode", ["signed", "adversarial"])
 def test_dequant_tensor_all_dtype_combinations(pkg, name, mode):

@@ -127,6 +127,45 @@ def test_oracle_matches_live_reference(pkg, name, mode):
     assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
 
 
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("name", ALL)
+def test_oracle_matches_live_reference_on_every_scale_bit_pattern(pkg, name):
+    """Pins the oracle on the WHOLE domain of the scale operands: all 65 536 bit patterns of every fp16 scale field of every format (random quants,
+    randomly signed other fields), the reference's own dequantize() on torch-CPU == the C oracle, in all three arithmetic modes.  (The GPU tests
+    hold the HIP path to the oracle on exactly these inputs: tests/test_gpu_parity.py::test_every_fp16_bit_pattern_of_every_scale_field.)"""
+    import torch
+    ref = reference.load_reference_dequant()
+    q = pkg.qtypes.Q[name]
+    bs, _ = pkg.qtypes.block_geometry(q)
+    pats = np.arange(65536, dtype=np.uint32)
+    for k, off in enumerate(pkg.qtypes.SCALE_FIELDS[q]):
+        blocks = pkg.synth.make_blocks(q, 65536, seed=4242 + k, mode="signed")       # the very blocks of the GPU test
+        blocks[:, off] = (pats & 0xFF).astype(np.uint8)
+        blocks[:, off + 1] = (pats >> 8).astype(np.uint8)
+        data = torch.from_numpy(blocks.reshape(-1).copy())
+        want = ref.dequantize(data, q, (65536 * bs,)).numpy()
+        assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want)), (name, off)
+        want32 = ref.dequantize(data, q, (65536 * bs,), dtype=torch.float32).numpy()
+        assert np.array_equal(_canon_f32(oracle.dequant_f32(q, blocks).view(np.uint32)), _canon_f32(want32.view(np.uint32))), (name, off, "f32")
+        wantbf = ref.dequantize(data, q, (65536 * bs,), dtype=torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(_canon_bf16(oracle.dequant_bf16_bits(q, blocks)), _canon_bf16(wantbf)), (name, off, "bf16")
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_oracle_matches_live_reference_on_every_q8_0_scale_quant_pair(pkg):
+    """Q8_0, the format the north star wants bit-exact: every one of the 65 536 x 256 (scale bits, quant) pairs, reference torch-CPU == oracle."""
+    import torch
+    ref = reference.load_reference_dequant()
+    q = pkg.qtypes.Q.Q8_0
+    blocks = np.zeros((65536 * 8, 34), dtype=np.uint8)
+    pats = np.repeat(np.arange(65536, dtype=np.uint32), 8)
+    blocks[:, 0] = (pats & 0xFF).astype(np.uint8)
+    blocks[:, 1] = (pats >> 8).astype(np.uint8)
+    blocks[:, 2:] = (np.arange(32, dtype=np.uint32)[None, :] + 32 * (np.arange(65536 * 8, dtype=np.uint32) % 8)[:, None]).astype(np.uint8)
+    want = ref.dequantize(torch.from_numpy(blocks.reshape(-1).copy()), q, (65536 * 8 * 32,)).numpy()
+    assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
+
+
 @pytest.mark.parametrize("mode", ["nominal", "signed", "adversarial", "raw"])
 def test_simd_throughput_leg_equals_the_soft_float_checker(pkg, golden_dir, mode):
     """oracle/ggq_oracle_simd.c (bench.py's cpu_baseline leg) == oracle/ggq_oracle.c, bit for bit, and hence
