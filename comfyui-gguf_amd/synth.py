@@ -94,3 +94,27 @@ def device_blocks(qtype, n_blocks, device, seed, mode="nominal"):
             vals = torch.where(torch.rand(n_blocks, device=device, generator=g) < 0.5, -vals, vals)
         blocks[:, off:off + 2] = vals.view(torch.uint8).reshape(n_blocks, 2)
     return blocks.reshape(-1)
+
+
+def q4_k_exhaustive_blocks(which="d", seed=0):
+    """Q4_K, the headline format, over the whole domain of one of its two products: 65 536 x 8 blocks in which ``which`` ("d" or "dmin") takes every
+    fp16 bit pattern, the 6-bit sub-block factor that multiplies it (``sc`` for d, ``m`` for dmin; dequant.py:129-139,180-195) takes every value 0..63
+    against each pattern, and every sub-block holds every 4-bit quant (in both nibble positions).  The other scale field is nominal with a random sign,
+    the other 6-bit factors random.  Returns (n_blocks, 144) uint8."""
+    rng = np.random.default_rng(seed)
+    n = 65536 * 8
+    blocks = np.zeros((n, 144), dtype=np.uint8)
+    pats = np.repeat(np.arange(65536, dtype=np.uint32), 8)
+    other = (rng.uniform(1e-4, 2e-3, size=n) * rng.choice([-1.0, 1.0], size=n)).astype(np.float16).view(np.uint16).astype(np.uint32)
+    d_bits, m_bits = (pats, other) if which == "d" else (other, pats)
+    blocks[:, 0], blocks[:, 1] = (d_bits & 0xFF).astype(np.uint8), (d_bits >> 8).astype(np.uint8)
+    blocks[:, 2], blocks[:, 3] = (m_bits & 0xFF).astype(np.uint8), (m_bits >> 8).astype(np.uint8)
+    swept = (8 * (np.arange(n, dtype=np.uint32) % 8))[:, None] + np.arange(8, dtype=np.uint32)[None, :]        # sub-block j of block b: 8 (b % 8) + j
+    rand6 = rng.integers(0, 64, size=(n, 8)).astype(np.uint32)
+    sc, mn = (swept, rand6) if which == "d" else (rand6, swept)
+    for j in range(4):                                                                                         # inverse of get_scale_min
+        blocks[:, 4 + j] = ((sc[:, j] & 63) | ((sc[:, j + 4] >> 4) << 6)).astype(np.uint8)
+        blocks[:, 8 + j] = ((mn[:, j] & 63) | ((mn[:, j + 4] >> 4) << 6)).astype(np.uint8)
+        blocks[:, 12 + j] = ((sc[:, j + 4] & 15) | ((mn[:, j + 4] & 15) << 4)).astype(np.uint8)
+    blocks[:, 16:] = ((np.arange(128, dtype=np.uint32) % 16) * 0x11).astype(np.uint8)[None, :]                  # byte = 0xkk: quant k in both nibbles
+    return blocks

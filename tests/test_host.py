@@ -589,3 +589,25 @@ def test_lookahead_bookkeeping_on_cpu(pkg, monkeypatch):
     del ws, w, outs
     gc.collect()
     assert ahead.stats()["tracked"] == 0 and tracked >= 7 and ahead.scratch_bytes() == 0
+
+
+def test_q4_k_exhaustive_generator_covers_what_it_says(pkg):
+    """synth.q4_k_exhaustive_blocks: every fp16 pattern of the swept scale field x every 6-bit factor that multiplies it x every quant in both nibbles
+    (decoded here with the reference's get_scale_min layout, dequant.py:129-139) -- the exhaustive parity tests stand on this."""
+    import numpy as np
+    for which, lo in (("d", 0), ("dmin", 2)):
+        b = pkg.synth.q4_k_exhaustive_blocks(which, seed=5)
+        assert b.shape == (65536 * 8, 144) and b.dtype == np.uint8
+        s = b[:, 4:16].astype(np.uint32)
+        sc, mn = np.zeros((b.shape[0], 8), np.uint32), np.zeros((b.shape[0], 8), np.uint32)
+        for j in range(4):
+            sc[:, j], mn[:, j] = s[:, j] & 63, s[:, j + 4] & 63
+            sc[:, j + 4] = (s[:, j + 8] & 15) | ((s[:, j] >> 6) << 4)
+            mn[:, j + 4] = (s[:, j + 8] >> 4) | ((s[:, j + 4] >> 6) << 4)
+        swept = sc if which == "d" else mn
+        assert np.array_equal(swept, (8 * (np.arange(b.shape[0]) % 8))[:, None] + np.arange(8)[None, :])          # 64 factors per pattern
+        field = b[:, lo].astype(np.uint32) | (b[:, lo + 1].astype(np.uint32) << 8)
+        assert np.array_equal(field, np.repeat(np.arange(65536), 8))                                               # every bit pattern, 8 blocks each
+        qs = b[0, 16:]
+        for p in range(4):                                                                                         # each 32-byte run feeds two sub-blocks
+            assert sorted(set(qs[32 * p:32 * p + 32] & 15)) == list(range(16)) and sorted(set(qs[32 * p:32 * p + 32] >> 4)) == list(range(16))

@@ -166,6 +166,19 @@ def test_oracle_matches_live_reference_on_every_q8_0_scale_quant_pair(pkg):
     assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
 
 
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("which", ["d", "dmin"])
+def test_oracle_matches_live_reference_on_every_q4_k_product(pkg, which):
+    """Q4_K over the whole domain of each of its two products (synth.q4_k_exhaustive_blocks: 65 536 scale patterns x 64 sub-block factors x 16 quants,
+    134 M elements): the reference's dequantize() on torch-CPU == the C oracle.  The GPU test holds the HIP path to the oracle on the same blocks."""
+    import torch
+    ref = reference.load_reference_dequant()
+    q = pkg.qtypes.Q.Q4_K
+    blocks = pkg.synth.q4_k_exhaustive_blocks(which, seed=5)
+    want = ref.dequantize(torch.from_numpy(blocks.reshape(-1)), q, (blocks.shape[0] * 256,)).numpy()
+    assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
+
+
 @pytest.mark.parametrize("mode", ["nominal", "signed", "adversarial", "raw"])
 def test_simd_throughput_leg_equals_the_soft_float_checker(pkg, golden_dir, mode):
     """oracle/ggq_oracle_simd.c (bench.py's cpu_baseline leg) == oracle/ggq_oracle.c, bit for bit, and hence
