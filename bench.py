@@ -27,6 +27,11 @@ Other workloads (not the driver's default; same JSON contract, one line):
   --workload sd35-t5     BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors (549 tensors), same treatment.
   --workload flux-gguf   the FLUX weight set written to a synthetic .gguf file, then parsed by the native
                          reader, streamed file -> pinned -> HBM and dequantized: the PCIe-inclusive rate.
+  --workload per-layer   the FLUX weight set the way the node drives it (ops.py:177): one dequantize_tensor() launch per tensor, bf16
+                         result -- standalone (graph-replayed, both store policies), eager, in context (unpack + F.linear per layer vs
+                         dense-resident weights), and the reference's own eager torch ops on the same device tensors beside it.
+
+The default run reports all of these as `workloads` sub-lines of the one JSON line, and `reference_on_this_gpu` for the headline pool.
 
 Prints ONE JSON line on rank 0.
 """
