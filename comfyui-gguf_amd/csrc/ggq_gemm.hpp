@@ -58,6 +58,10 @@ constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 
 #ifndef GGQ_GT_XRING
 #define GGQ_GT_XRING 1      /* a third x buffer where it fits: x tiles requested two K-steps ahead (0 = one step ahead); A/B builds */
 #endif
+#ifndef GGQ_GT_SETPRIO
+#define GGQ_GT_SETPRIO 1    /* s_setprio around one half of a K-step: 1 = the MFMA half (fragment reads + MFMAs) runs at priority 1 -- 3-5 % faster at every
+                               shape, profiles/r03_gemm_tile_setprio.json; 2 = the decode half (level); 0 = none; A/B builds */
+#endif
 #ifndef GGQ_GT_PINGPONG
 #define GGQ_GT_PINGPONG 1   /* the waves of a SIMD alternate the order of decode and MFMAs (0 = same order in all waves); A/B builds */
 #endif
@@ -160,6 +164,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
     const uint32_t dswz = gt_swz(drow);
     auto decode = [&](uint32_t step, uint8_t* wdst) {
+#if GGQ_GT_SETPRIO == 2            /* A/B builds: the reverse -- the decoding wave outranks the one that feeds the matrix pipe */
+        __builtin_amdgcn_s_setprio(1);
+#endif
         const uint32_t span = step / STEPS, ks = step % STEPS;
         const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
         const uint8_t* wspan = stg + (GG::DBUF ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
@@ -171,6 +178,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
             weights8<F, OUT>(f, w);
             *reinterpret_cast<u32x4*>(wdst + drow * GT_PITCH + ((c ^ dswz) * 16u)) = u32x4{w[0], w[1], w[2], w[3]};
         }
+#if GGQ_GT_SETPRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- x tile by LDS-DMA: unit u = t + THREADS i -> (row u / 4, 16-byte piece u % 4); the LDS image is lane-linear, so the XOR swizzle goes
@@ -199,6 +209,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 
     // one k-slice of 16: the wave's 2 weight fragments and MT x fragments (one ds_read_b128 each), then its 2 MT MFMAs
     auto mma = [&](const uint8_t* xs, const uint8_t* ws) {
+#if GGQ_GT_SETPRIO == 1            /* the wave that feeds the matrix pipe outranks the ones that decode */
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
@@ -212,6 +225,9 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
         }
+#if GGQ_GT_SETPRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- prologue: span 0 staged, x tiles 0 and 1 requested, weight tile 0 decoded
