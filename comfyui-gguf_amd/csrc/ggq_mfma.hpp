@@ -30,6 +30,10 @@
 
 #include "ggq_linear.hpp"
 
+#ifndef GGQ_MF_SETPRIO
+#define GGQ_MF_SETPRIO 0     /* s_setprio 1 around the MFMAs of a k-step: 4-20 % SLOWER here (1-4 MFMAs per toggle; EXPERIMENTS A2c), unlike the shared-tile kernel; A/B builds */
+#endif
+
 namespace ggq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -126,8 +130,14 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
         uint32_t w[4];
         weights8<F, OUT>(f, w);
         const u32x4 wb{w[0], w[1], w[2], w[3]};
+#if GGQ_MF_SETPRIO
+        __builtin_amdgcn_s_setprio(1);             // A/B builds: a wave with MFMAs to issue outranks the ones that decode
+#endif
 #pragma unroll
         for (int mb = 0; mb < MB; mb++) acc[mb] = mfma32<OUT>(xa[mb], wb, acc[mb]);
+#if GGQ_MF_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     u32x4 pf[G::NUW];
