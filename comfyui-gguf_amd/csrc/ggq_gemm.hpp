@@ -62,6 +62,10 @@ constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 
 #define GGQ_GT_SETPRIO 1    /* s_setprio around one half of a K-step: 1 = the MFMA half (fragment reads + MFMAs) runs at priority 1 -- 3-5 % faster at every
                                shape, profiles/r03_gemm_tile_setprio.json; 2 = the decode half (level); 0 = none; A/B builds */
 #endif
+#ifndef GGQ_GT_PONG_MASK
+#define GGQ_GT_PONG_MASK 0x9 /* bit s: the wave in slot s of its SIMD (wave >> 2) runs the MFMAs of a K-step BEFORE its decode.  Slots {0, 3} measured best
+                               (3 % over the alternating 0xA, profiles/r03_gemm_tile_wave_order.json); A/B builds */
+#endif
 #ifndef GGQ_GT_PINGPONG
 #define GGQ_GT_PINGPONG 1   /* the waves of a SIMD alternate the order of decode and MFMAs (0 = same order in all waves); A/B builds */
 #endif
@@ -220,10 +224,16 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
             for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + ((uint32_t)(32 * MT) * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
+#if GGQ_GT_SETPRIO == 3            /* A/B builds: priority 1 only while the MFMAs issue, not for the fragment reads */
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) acc[nt][mt] = mfma32<OUT>(wa[nt], xb[mt], acc[nt][mt]);
+#if GGQ_GT_SETPRIO == 3
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
 #if GGQ_GT_SETPRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -314,7 +324,8 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         kstep(step, T0{}, pong_tag, std::true_type{});
         kstep(step + 1, T1{}, pong_tag, std::false_type{});        // the last step has nothing left to decode
     };
-    if ((wave >> 2) & 1) main_loop(std::true_type{});
+    // which of a SIMD's waves (slots wave >> 2 = 0 .. WM*4/4-1) run their MFMAs first: GGQ_GT_PONG_MASK bit s = slot s does (0x9: slots 0 and 3)
+    if ((GGQ_GT_PONG_MASK >> (wave >> 2)) & 1) main_loop(std::true_type{});
     else main_loop(std::false_type{});
     if constexpr (XR == 3) dma_fence();                      // nothing may still be landing in LDS when the epilogue reuses it
 
