@@ -62,6 +62,10 @@ constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 
 #define GGQ_GT_SETPRIO 1    /* s_setprio around one half of a K-step: 1 = the MFMA half (fragment reads + MFMAs) runs at priority 1 -- 3-5 % faster at every
                                shape, profiles/r03_gemm_tile_setprio.json; 2 = the decode half (level); 0 = none; A/B builds */
 #endif
+#ifndef GGQ_GT_SHARED_SCALE
+#define GGQ_GT_SHARED_SCALE 1 /* Q4_K / Q5_K: the (d*sc, dmin*mn) pair of a sub-block is computed once per SPAN by one of the row's four lanes and handed round
+                                 by ds_bpermute, instead of by every lane in every K-step (same ops, same bits; -10 VALU of 55 per K-step); 0 = generic path; A/B builds */
+#endif
 #ifndef GGQ_GT_PONG_MASK
 #define GGQ_GT_PONG_MASK 0x9 /* bit s: the wave in slot s of its SIMD (wave >> 2) runs the MFMAs of a K-step BEFORE its decode.  Slots {0, 3} measured best
                                (3 % over the alternating 0xA, profiles/r03_gemm_tile_wave_order.json); A/B builds */
@@ -75,6 +79,11 @@ GGQ_DEV uint32_t gt_swz(uint32_t row) { return ((row >> 3) & 3u) ^ ((row >> 1) &
 // How much of K is staged at a time: one super-block (256 elements) for the K-quants -- `fields` wants the whole block -- and 4 blocks (128
 // elements) for the 32-element legacy formats, whose staging then fits twice beside the operand tiles (Q8_0: 2 x 40 KiB) so that they too are
 // filled by LDS-DMA instead of through registers.
+// formats whose K-step of 32 is exactly one sub-block with one (scale, min) pair: the pair can be precomputed per span and shared by the row's lanes
+template <class F> struct SpanScales { static constexpr bool V = false; };
+template <> struct SpanScales<FmtQ4_K> { static constexpr bool V = true; };
+template <> struct SpanScales<FmtQ5_K> { static constexpr bool V = true; };
+
 template <class F> struct TileSpan {
     static constexpr int SPAN = (F::BS == 32) ? 128 : 256;
     static constexpr int STEPS = SPAN / GT_BK;                                    // K-steps per staged span
@@ -167,6 +176,22 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     const uint32_t wrow = (n0 + drow < n_rows) ? n0 + drow : n_rows - 1;
     const uint64_t wrow_off = (uint64_t)wrow * row_bytes;
     const uint32_t dswz = gt_swz(drow);
+    // Q4_K / Q5_K with one chunk per thread: lane c of a row's four holds the (d*sc, dmin*mn) pairs of sub-blocks c and c + 4 of the current span
+    constexpr bool SHARED = GGQ_GT_SHARED_SCALE && SpanScales<F>::V && CPT == 1 && G::SPAN == 256;
+    uint32_t pre0 = 0, pre1 = 0;
+    const uint32_t quad_lane0 = ((uint32_t)lane & ~3u) << 2;                        // ds_bpermute address of the row's first lane
+    auto prescale = [&](uint32_t span) {
+        if constexpr (SHARED) {
+            const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
+            const uint8_t* blk = stg + (GG::DBUF ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
+            const u32x4 hdr = *reinterpret_cast<const u32x4*>(blk);                 // [d][dmin][scales 12]
+            int32_t sc, mn;
+            k_scale_min(hdr, (int)dc0, sc, mn);
+            pre0 = as_u32(as_h2(hdr.x) * ints_h2((uint32_t)sc | ((uint32_t)mn << 16), 0.0f));      // the very expression of quad_f16<K_SCMN>
+            k_scale_min(hdr, (int)dc0 + 4, sc, mn);
+            pre1 = as_u32(as_h2(hdr.x) * ints_h2((uint32_t)sc | ((uint32_t)mn << 16), 0.0f));
+        }
+    };
     auto decode = [&](uint32_t step, uint8_t* wdst) {
 #if GGQ_GT_SETPRIO == 2            /* A/B builds: the reverse -- the decoding wave outranks the one that feeds the matrix pipe */
         __builtin_amdgcn_s_setprio(1);
@@ -174,13 +199,29 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         const uint32_t span = step / STEPS, ks = step % STEPS;
         const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
         const uint8_t* wspan = stg + (GG::DBUF ? (span & 1u) * (uint32_t)GG::STAGING : 0u) + drow * (uint32_t)G::ROW_STRIDE + a;
+        if constexpr (SHARED) {
+            // sub-block ks of the span: its pair sits in lane ks % 4 of the row, slot ks / 4
+            const uint32_t mine = (ks & 4u) ? pre1 : pre0;
+            const h2 dlml = as_h2((uint32_t)__builtin_amdgcn_ds_bpermute((int)(quad_lane0 | ((ks & 3u) << 2)), (int)mine));
+            const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+            const uint32_t j = ks * 4u + dc0;
+            const Fields f = F::template fields<true>(wspan, (int)j);             // only the quants are used: the scale decode in there is dead code
+            const H2x2 q0 = fields_h2(f.t0, (float)F::BIAS), q1 = fields_h2(f.t1, (float)F::BIAS);
+            uint32_t w[4] = {as_u32(dl * q0.a - ml), as_u32(dl * q0.b - ml), as_u32(dl * q1.a - ml), as_u32(dl * q1.b - ml)};
+            if constexpr (OUT == OUT_BF16) {
 #pragma unroll
-        for (int s = 0; s < CPT; s++) {
-            const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
-            const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, (int)(j % CPB));
-            uint32_t w[4];
-            weights8<F, OUT>(f, w);
-            *reinterpret_cast<u32x4*>(wdst + drow * GT_PITCH + ((c ^ dswz) * 16u)) = u32x4{w[0], w[1], w[2], w[3]};
+                for (int k = 0; k < 4; k++) w[k] = h2_to_bf16x2(w[k]);
+            }
+            *reinterpret_cast<u32x4*>(wdst + drow * GT_PITCH + ((dc0 ^ dswz) * 16u)) = u32x4{w[0], w[1], w[2], w[3]};
+        } else {
+#pragma unroll
+            for (int s = 0; s < CPT; s++) {
+                const uint32_t c = dc0 + (uint32_t)s, j = ks * 4u + c;                 // chunk of the 256-element span
+                const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, (int)(j % CPB));
+                uint32_t w[4];
+                weights8<F, OUT>(f, w);
+                *reinterpret_cast<u32x4*>(wdst + drow * GT_PITCH + ((c ^ dswz) * 16u)) = u32x4{w[0], w[1], w[2], w[3]};
+            }
         }
 #if GGQ_GT_SETPRIO == 2
         __builtin_amdgcn_s_setprio(0);
@@ -257,6 +298,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     xdma(0u, xt);
     dma_fence();
     if (GG::DBUF && n_spans > 1) dma_span(1u, 1u);
+    prescale(0u);
     decode(0u, wt);
     xdma(n_steps > 1 ? 1u : 0u, xt + GT_TILE);
     dma_fence();
@@ -284,6 +326,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
                 dma_span(span, 0u);                     // one buffer: refill it now and wait for it (once per span)
                 dma_fence();
             }
+            prescale(span);                             // the new span's bytes are in LDS (fenced steps ago, or just now)
         }
         if constexpr (DECODE) {
             // x tile of step + 2 (XR = 3: two K-steps to land) or of step + 1; clamped at the end: a harmless re-read into a buffer nobody reads
