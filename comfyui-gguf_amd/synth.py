@@ -96,14 +96,16 @@ def device_blocks(qtype, n_blocks, device, seed, mode="nominal"):
     return blocks.reshape(-1)
 
 
-def q4_k_exhaustive_blocks(which="d", seed=0):
-    """Q4_K, the headline format, over the whole domain of one of its two products: 65 536 x 8 blocks in which ``which`` ("d" or "dmin") takes every
-    fp16 bit pattern, the 6-bit sub-block factor that multiplies it (``sc`` for d, ``m`` for dmin; dequant.py:129-139,180-195) takes every value 0..63
-    against each pattern, and every sub-block holds every 4-bit quant (in both nibble positions).  The other scale field is nominal with a random sign,
-    the other 6-bit factors random.  Returns (n_blocks, 144) uint8."""
+def k_scmn_exhaustive_blocks(qtype, which="d", seed=0):
+    """Q4_K / Q5_K over the whole domain of one of their two products: 65 536 x 8 blocks in which ``which`` ("d" or "dmin") takes every fp16 bit
+    pattern, the 6-bit sub-block factor that multiplies it (``sc`` for d, ``m`` for dmin; dequant.py:129-139,159-195) takes every value 0..63 against
+    each pattern, and every sub-block holds every quant value (16 for Q4_K, in both nibble positions; 32 for Q5_K).  The other scale field is nominal
+    with a random sign, the other 6-bit factors random.  Returns (n_blocks, type_size) uint8."""
+    qtype = GGMLQuantizationType(int(qtype))
+    ts = {GGMLQuantizationType.Q4_K: 144, GGMLQuantizationType.Q5_K: 176}[qtype]
     rng = np.random.default_rng(seed)
     n = 65536 * 8
-    blocks = np.zeros((n, 144), dtype=np.uint8)
+    blocks = np.zeros((n, ts), dtype=np.uint8)
     pats = np.repeat(np.arange(65536, dtype=np.uint32), 8)
     other = (rng.uniform(1e-4, 2e-3, size=n) * rng.choice([-1.0, 1.0], size=n)).astype(np.float16).view(np.uint16).astype(np.uint32)
     d_bits, m_bits = (pats, other) if which == "d" else (other, pats)
@@ -116,5 +118,12 @@ def q4_k_exhaustive_blocks(which="d", seed=0):
         blocks[:, 4 + j] = ((sc[:, j] & 63) | ((sc[:, j + 4] >> 4) << 6)).astype(np.uint8)
         blocks[:, 8 + j] = ((mn[:, j] & 63) | ((mn[:, j + 4] >> 4) << 6)).astype(np.uint8)
         blocks[:, 12 + j] = ((sc[:, j + 4] & 15) | ((mn[:, j + 4] & 15) << 4)).astype(np.uint8)
-    blocks[:, 16:] = ((np.arange(128, dtype=np.uint32) % 16) * 0x11).astype(np.uint8)[None, :]                  # byte = 0xkk: quant k in both nibbles
+    blocks[:, ts - 128:] = ((np.arange(128, dtype=np.uint32) % 16) * 0x11).astype(np.uint8)[None, :]             # byte = 0xkk: nibble k in both positions
+    if qtype == GGMLQuantizationType.Q5_K:
+        blocks[:, 16:48] = np.where(np.arange(32) >= 16, 0xFF, 0x00).astype(np.uint8)[None, :]                  # qh[l]: high bit of element l of EVERY sub-block = (l >= 16)
     return blocks
+
+
+def q4_k_exhaustive_blocks(which="d", seed=0):
+    """:func:`k_scmn_exhaustive_blocks` for Q4_K, the headline format."""
+    return k_scmn_exhaustive_blocks(GGMLQuantizationType.Q4_K, which, seed)

@@ -176,18 +176,20 @@ def test_every_scale_times_every_quant_value(pkg, name):
 
 
 @pytest.mark.parametrize("which", ["d", "dmin"])
-def test_q4_k_every_scale_pattern_times_every_subblock_factor_times_every_quant(pkg, which):
-    """Q4_K (the headline format): every (fp16 scale bit pattern, 6-bit sub-block factor, 4-bit quant) triple of the d*sc*q product -- 65 536 x 64 x 16,
-    134 M elements -- and every (dmin pattern, m) pair of the subtrahend; fp16 arithmetic -> fp16 and bf16 results, bit-exact against the oracle."""
-    q = pkg.qtypes.Q.Q4_K
-    blocks = pkg.synth.q4_k_exhaustive_blocks(which, seed=5)
+@pytest.mark.parametrize("name", ["Q4_K", "Q5_K"])
+def test_q4_k_every_scale_pattern_times_every_subblock_factor_times_every_quant(pkg, name, which):
+    """Q4_K (the headline format) and Q5_K (the other format of FLUX's Q4_K_M mix): every (fp16 scale bit pattern, 6-bit sub-block factor, quant) triple of
+    the d*sc*q product -- 65 536 x 64 x 16 (x 32 for Q5_K), 134 M elements -- and every (dmin pattern, m) pair of the subtrahend; fp16 arithmetic -> fp16
+    and bf16 results, bit-exact against the oracle."""
+    q = pkg.qtypes.Q[name]
+    blocks = pkg.synth.k_scmn_exhaustive_blocks(q, which, seed=5)
     t = _carrier(pkg, blocks, q)
     want = oracle.dequant_f16(q, blocks)
     got = pkg.dequant.dequantize_tensor(t, torch.float16)
     g, w = oracle.canon_nan_f16(_bits16(got)), oracle.canon_nan_f16(want)
     if not np.array_equal(g, w):
         bad = np.flatnonzero(g != w)
-        raise AssertionError(f"Q4_K {which}: {bad.size} of {g.size} elements differ, first in block {bad[0] // 256} element {bad[0] % 256}")
+        raise AssertionError(f"{name} {which}: {bad.size} of {g.size} elements differ, first in block {bad[0] // 256} element {bad[0] % 256}")
     del got, g, w
     got = pkg.dequant.dequantize_tensor(t, torch.bfloat16)
     assert np.array_equal(_canon(_raw(got), "bf16"), _canon(oracle.dequant_tensor(q, blocks, "f16", "bf16"), "bf16"))

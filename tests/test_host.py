@@ -611,3 +611,9 @@ def test_q4_k_exhaustive_generator_covers_what_it_says(pkg):
         qs = b[0, 16:]
         for p in range(4):                                                                                         # each 32-byte run feeds two sub-blocks
             assert sorted(set(qs[32 * p:32 * p + 32] & 15)) == list(range(16)) and sorted(set(qs[32 * p:32 * p + 32] >> 4)) == list(range(16))
+    b5 = pkg.synth.k_scmn_exhaustive_blocks(pkg.qtypes.Q.Q5_K, "d", seed=5)
+    assert b5.shape == (65536 * 8, 176)
+    qh, qs = b5[0, 16:48].astype(np.uint32), b5[0, 48:].astype(np.uint32)
+    for sb in range(8):                                                                                            # dequant.py:159-178: q = nibble | bit sb of qh[l] << 4
+        nib = (qs[32 * (sb // 2):32 * (sb // 2) + 32] >> (4 * (sb & 1))) & 15
+        assert sorted(set((nib | (((qh >> sb) & 1) << 4)).tolist())) == list(range(32))

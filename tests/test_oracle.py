@@ -168,13 +168,14 @@ def test_oracle_matches_live_reference_on_every_q8_0_scale_quant_pair(pkg):
 
 @pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
 @pytest.mark.parametrize("which", ["d", "dmin"])
-def test_oracle_matches_live_reference_on_every_q4_k_product(pkg, which):
-    """Q4_K over the whole domain of each of its two products (synth.q4_k_exhaustive_blocks: 65 536 scale patterns x 64 sub-block factors x 16 quants,
+@pytest.mark.parametrize("name", ["Q4_K", "Q5_K"])
+def test_oracle_matches_live_reference_on_every_q4_k_product(pkg, name, which):
+    """Q4_K / Q5_K over the whole domain of each of their two products (synth.k_scmn_exhaustive_blocks: 65 536 scale patterns x 64 sub-block factors x 16 quants,
     134 M elements): the reference's dequantize() on torch-CPU == the C oracle.  The GPU test holds the HIP path to the oracle on the same blocks."""
     import torch
     ref = reference.load_reference_dequant()
-    q = pkg.qtypes.Q.Q4_K
-    blocks = pkg.synth.q4_k_exhaustive_blocks(which, seed=5)
+    q = pkg.qtypes.Q[name]
+    blocks = pkg.synth.k_scmn_exhaustive_blocks(q, which, seed=5)
     want = ref.dequantize(torch.from_numpy(blocks.reshape(-1)), q, (blocks.shape[0] * 256,)).numpy()
     assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
 
