@@ -62,6 +62,9 @@ constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 
 #define GGQ_GT_SETPRIO 1    /* s_setprio around one half of a K-step: 1 = the MFMA half (fragment reads + MFMAs) runs at priority 1 -- 3-5 % faster at every
                                shape, profiles/r03_gemm_tile_setprio.json; 2 = the decode half (level); 0 = none; A/B builds */
 #endif
+#ifndef GGQ_GT_PRIO_LEVEL
+#define GGQ_GT_PRIO_LEVEL 1  /* the priority (1..3) of the MFMA half; A/B builds */
+#endif
 #ifndef GGQ_GT_SHARED_SCALE
 #define GGQ_GT_SHARED_SCALE 1 /* Q4_K / Q5_K: the (d*sc, dmin*mn) pair of a sub-block is computed once per SPAN by one of the row's four lanes and handed round
                                  by ds_bpermute, instead of by every lane in every K-step (same ops, same bits; -10 VALU of 55 per K-step); 0 = generic path; A/B builds */
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     // one k-slice of 16: the wave's 2 weight fragments and MT x fragments (one ds_read_b128 each), then its 2 MT MFMAs
     auto mma = [&](const uint8_t* xs, const uint8_t* ws) {
 #if GGQ_GT_SETPRIO == 1            /* the wave that feeds the matrix pipe outranks the ones that decode */
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(GGQ_GT_PRIO_LEVEL);
 #endif
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
