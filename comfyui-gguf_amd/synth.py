@@ -127,3 +127,60 @@ def k_scmn_exhaustive_blocks(qtype, which="d", seed=0):
 def q4_k_exhaustive_blocks(which="d", seed=0):
     """:func:`k_scmn_exhaustive_blocks` for Q4_K, the headline format."""
     return k_scmn_exhaustive_blocks(GGMLQuantizationType.Q4_K, which, seed)
+
+
+def k_exhaustive_blocks(qtype, which="d", seed=0, d_range=None):
+    """The super-block formats over the whole domain of a scale product: every fp16 bit pattern of the scale field ``which`` ("d"; "dmin" where the
+    format has one) against EVERY value of the integer sub-block factor that multiplies it, with every quant value present in every sub-block (Q6_K:
+    random quants -- 64 values do not fit 16 elements).  Blocks per pattern: Q2_K 1 (16 sub-blocks = the 16 4-bit factors), Q3_K 4 (64 6-bit scales),
+    Q4_K / Q5_K / IQ4_XS 8 (64 6-bit factors), Q6_K 16 (256 int8 scales).  ``d_range`` = (lo, hi) restricts the patterns to [lo, hi) so that the big
+    ones can be walked in pieces.  Layouts: dequant.py:141-285.  Returns (n_blocks, type_size) uint8."""
+    Q = GGMLQuantizationType
+    qtype = Q(int(qtype))
+    if qtype in (Q.Q4_K, Q.Q5_K):
+        b = k_scmn_exhaustive_blocks(qtype, which, seed)
+        return b if d_range is None else b[8 * d_range[0]:8 * d_range[1]]
+    lo, hi = d_range or (0, 65536)
+    reps = {Q.Q2_K: 1, Q.Q3_K: 4, Q.Q6_K: 16, Q.IQ4_XS: 8}[qtype]
+    ts = GGML_QUANT_SIZES[qtype][1]
+    rng = np.random.default_rng(seed)
+    n = (hi - lo) * reps
+    blocks = np.zeros((n, ts), dtype=np.uint8)
+    pats = np.repeat(np.arange(lo, hi, dtype=np.uint32), reps)
+    rep = np.arange(n, dtype=np.uint32) % reps
+    other = (rng.uniform(1e-4, 2e-3, size=n) * rng.choice([-1.0, 1.0], size=n)).astype(np.float16).view(np.uint16).astype(np.uint32)
+
+    def put16(off, bits):
+        blocks[:, off], blocks[:, off + 1] = (bits & 0xFF).astype(np.uint8), (bits >> 8).astype(np.uint8)
+
+    crumbs = ((np.arange(32, dtype=np.uint32) % 4) * 0x55).astype(np.uint8)                     # byte l: all four 2-bit fields = l % 4
+    if qtype == Q.Q2_K:                                                                          # [scales 16][qs 64][d][dmin]; scales = sc | m << 4
+        if which not in ("d", "dmin"):
+            raise ValueError(which)
+        swept, rand4 = np.arange(16, dtype=np.uint32)[None, :].repeat(n, 0), rng.integers(0, 16, size=(n, 16)).astype(np.uint32)
+        sc, m = (swept, rand4) if which == "d" else (rand4, swept)
+        blocks[:, 0:16] = (sc | (m << 4)).astype(np.uint8)
+        blocks[:, 16:80] = np.tile(crumbs, 2)[None, :]
+        put16(80, pats if which == "d" else other)
+        put16(82, other if which == "d" else pats)
+    elif qtype == Q.Q3_K:                                                                        # [hmask 32][qs 64][scales 12][d]; 6-bit scales, see dequant.py:203-210
+        v = (16 * rep)[:, None] + np.arange(16, dtype=np.uint32)[None, :]                        # stored scale value of sub-block j (0..63 = -32..31)
+        for k in range(8):
+            blocks[:, 96 + k] = ((v[:, k] & 15) | ((v[:, k + 8] & 15) << 4)).astype(np.uint8)
+        for k in range(4):
+            blocks[:, 104 + k] = sum((((v[:, k + 4 * g] >> 4) & 3) << (2 * g)) for g in range(4)).astype(np.uint8)
+        blocks[:, 0:32] = np.where((np.arange(32) >> 2) & 1, 0xFF, 0x00).astype(np.uint8)[None, :]   # hmask[l]: the high bit of element l in every 32-run
+        blocks[:, 32:96] = np.tile(crumbs, 2)[None, :]
+        put16(108, pats)
+    elif qtype == Q.Q6_K:                                                                        # [ql 128][qh 64][scales i8 x16][d]
+        blocks[:, 0:192] = rng.integers(0, 256, size=(n, 192), dtype=np.uint8)
+        blocks[:, 192:208] = ((16 * rep)[:, None] + np.arange(16, dtype=np.uint32)[None, :]).astype(np.uint8)   # all 256 int8 bit patterns
+        put16(208, pats)
+    else:                                                                                        # IQ4_XS: [d][scales_h u16][scales_l 4][qs 128]
+        ls = (8 * rep)[:, None] + np.arange(8, dtype=np.uint32)[None, :]                         # stored 6-bit scale of sub-block ib
+        put16(0, pats)
+        put16(2, sum(((ls[:, ib] >> 4) & 3) << (2 * ib) for ib in range(8)))
+        for k in range(4):
+            blocks[:, 4 + k] = ((ls[:, 2 * k] & 15) | ((ls[:, 2 * k + 1] & 15) << 4)).astype(np.uint8)
+        blocks[:, 8:136] = np.tile((np.arange(16, dtype=np.uint32) * 0x11).astype(np.uint8), 8)[None, :]        # byte k of a sub-block = 0xkk
+    return blocks

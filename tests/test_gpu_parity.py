@@ -195,6 +195,23 @@ def test_q4_k_every_scale_pattern_times_every_subblock_factor_times_every_quant(
     assert np.array_equal(_canon(_raw(got), "bf16"), _canon(oracle.dequant_tensor(q, blocks, "f16", "bf16"), "bf16"))
 
 
+@pytest.mark.parametrize("name,which", [("Q2_K", "d"), ("Q2_K", "dmin"), ("Q3_K", "d"), ("IQ4_XS", "d"), ("Q6_K", "d")])
+def test_every_scale_pattern_times_every_subblock_factor_other_k_formats(pkg, name, which):
+    """The remaining super-block formats over the whole domain of their scale products (synth.k_exhaustive_blocks): every fp16 bit pattern of d (and of
+    dmin for Q2_K) x every value of the integer sub-block factor (16 4-bit, 64 6-bit, 256 int8) x every quant value in every sub-block (Q6_K: random
+    quants); fp16 arithmetic, bit-exact against the oracle.  Q6_K (268 M elements) is walked in four pieces."""
+    q = pkg.qtypes.Q[name]
+    pieces = [(k * 16384, (k + 1) * 16384) for k in range(4)] if name == "Q6_K" else [None]
+    for rng_ in pieces:
+        blocks = pkg.synth.k_exhaustive_blocks(q, which, seed=5, d_range=rng_)
+        got = pkg.dequant.dequantize_tensor(_carrier(pkg, blocks, q), torch.float16)
+        g, w = oracle.canon_nan_f16(_bits16(got)), oracle.canon_nan_f16(oracle.dequant_f16(q, blocks))
+        if not np.array_equal(g, w):
+            bad = np.flatnonzero(g != w)
+            raise AssertionError(f"{name} {which} {rng_}: {bad.size} of {g.size} elements differ, first in block {bad[0] // 256} element {bad[0] % 256}")
+        del got, g, w
+
+
 @pytest.mark.parametrize("name", ALL)
 @pytest.mark.parametrize("mode", ["signed", "adversarial"])
 def test_dequant_tensor_all_dtype_combinations(pkg, name, mode):

@@ -617,3 +617,41 @@ def test_q4_k_exhaustive_generator_covers_what_it_says(pkg):
     for sb in range(8):                                                                                            # dequant.py:159-178: q = nibble | bit sb of qh[l] << 4
         nib = (qs[32 * (sb // 2):32 * (sb // 2) + 32] >> (4 * (sb & 1))) & 15
         assert sorted(set((nib | (((qh >> sb) & 1) << 4)).tolist())) == list(range(32))
+
+
+def test_k_exhaustive_generators_cover_what_they_say(pkg):
+    """synth.k_exhaustive_blocks for Q2_K / Q3_K / Q6_K / IQ4_XS, decoded here with the layouts of dequant.py:141-285: every scale bit pattern, every
+    integer sub-block factor against each, every quant value in every sub-block."""
+    import numpy as np
+    Q, gen = pkg.qtypes.Q, pkg.synth.k_exhaustive_blocks
+    for which, off in (("d", 80), ("dmin", 82)):
+        b = gen(Q.Q2_K, which, seed=1)
+        assert b.shape == (65536, 84)
+        swept = (b[:, 0:16] & 15) if which == "d" else (b[:, 0:16] >> 4)
+        assert (swept == np.arange(16)[None, :]).all()
+        assert ((b[:, off].astype(np.uint32) | (b[:, off + 1].astype(np.uint32) << 8)) == np.arange(65536)).all()
+        qs = b[0, 16:80].astype(int)
+        el = np.array([(qs[32 * (e // 128) + e % 32] >> (2 * ((e % 128) // 32))) & 3 for e in range(256)])
+        assert all(sorted(set(el[16 * j:16 * j + 16].tolist())) == [0, 1, 2, 3] for j in range(16))
+    b = gen(Q.Q3_K, "d", seed=1)
+    assert b.shape == (65536 * 4, 110)
+    scb, v = b[:, 96:108].astype(np.uint32), np.zeros((b.shape[0], 16), np.uint32)
+    for j in range(16):
+        v[:, j] = ((scb[:, j] & 15) if j < 8 else (scb[:, j - 8] >> 4)) | (((scb[:, 8 + j % 4] >> (2 * (j // 4))) & 3) << 4)
+    assert (v == (16 * (np.arange(b.shape[0]) % 4))[:, None] + np.arange(16)[None, :]).all()
+    assert ((b[:, 108].astype(np.uint32) | (b[:, 109].astype(np.uint32) << 8)) == np.repeat(np.arange(65536), 4)).all()
+    hm, qs = b[0, 0:32].astype(int), b[0, 32:96].astype(int)
+    q3 = np.array([((qs[32 * (e // 128) + e % 32] >> (2 * ((e % 128) // 32))) & 3) - (0 if (hm[e % 32] >> (e // 32)) & 1 else 4) for e in range(256)])
+    assert all(sorted(set(q3[16 * j:16 * j + 16].tolist())) == list(range(-4, 4)) for j in range(16))
+    b = gen(Q.Q6_K, "d", seed=1, d_range=(100, 104))
+    assert b.shape == (64, 210) and (b[:, 192:208].astype(np.uint32) == (16 * (np.arange(64) % 16))[:, None] + np.arange(16)[None, :]).all()
+    assert ((b[:, 208].astype(np.uint32) | (b[:, 209].astype(np.uint32) << 8)) == np.repeat(np.arange(100, 104), 16)).all()
+    b = gen(Q.IQ4_XS, "d", seed=1)
+    assert b.shape == (65536 * 8, 136)
+    sh, sl = b[:, 2].astype(np.uint32) | (b[:, 3].astype(np.uint32) << 8), b[:, 4:8].astype(np.uint32)
+    ls = np.stack([((sl[:, ib // 2] >> (4 * (ib % 2))) & 15) | (((sh >> (2 * ib)) & 3) << 4) for ib in range(8)], 1)
+    assert (ls == (8 * (np.arange(b.shape[0]) % 8))[:, None] + np.arange(8)[None, :]).all()
+    assert ((b[:, 0].astype(np.uint32) | (b[:, 1].astype(np.uint32) << 8)) == np.repeat(np.arange(65536), 8)).all()
+    for ib in range(8):
+        run = b[0, 8 + 16 * ib:8 + 16 * ib + 16]
+        assert sorted(set((run & 15).tolist())) == list(range(16)) and sorted(set((run >> 4).tolist())) == list(range(16))

@@ -180,6 +180,22 @@ def test_oracle_matches_live_reference_on_every_q4_k_product(pkg, name, which):
     assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want))
 
 
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("name,which", [("Q2_K", "d"), ("Q2_K", "dmin"), ("Q3_K", "d"), ("IQ4_XS", "d"), ("Q6_K", "d")])
+def test_oracle_matches_live_reference_on_every_scale_product_other_k_formats(pkg, name, which):
+    """synth.k_exhaustive_blocks (every scale bit pattern x every integer sub-block factor x the quants): the reference's dequantize() on torch-CPU == the
+    C oracle for the remaining super-block formats.  Q6_K (256 int8 scales per pattern: 268 M elements) is walked in eight pieces to bound memory."""
+    import torch
+    ref = reference.load_reference_dequant()
+    q = pkg.qtypes.Q[name]
+    pieces = [(k * 8192, (k + 1) * 8192) for k in range(8)] if name == "Q6_K" else [None]
+    for rng_ in pieces:
+        blocks = pkg.synth.k_exhaustive_blocks(q, which, seed=5, d_range=rng_)
+        want = ref.dequantize(torch.from_numpy(blocks.reshape(-1)), q, (blocks.shape[0] * 256,)).numpy()
+        assert np.array_equal(oracle.canon_nan_f16(oracle.dequant_f16(q, blocks)), oracle.canon_nan_f16(want)), (name, which, rng_)
+        del want
+
+
 @pytest.mark.parametrize("mode", ["nominal", "signed", "adversarial", "raw"])
 def test_simd_throughput_leg_equals_the_soft_float_checker(pkg, golden_dir, mode):
     """oracle/ggq_oracle_simd.c (bench.py's cpu_baseline leg) == oracle/ggq_oracle.c, bit for bit, and hence
