@@ -18,7 +18,11 @@ Headline workload: Q4_K (the north-star target format, BASELINE.json configs[2])
 Multi-GPU (driver: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...):
 one process per GPU, WEAK scaling -- the global tensor list is N pools, partitioned by
 comfyui-gguf_amd/sharding.py; no collective on the data path.  torch.distributed (RCCL) only
-fences the timed region (barrier) and takes the MAX time over ranks.
+fences the timed region (barrier) and takes the MAX time over ranks.  The N > 1 line is self-proving:
+`world` lists N distinct devices (the run refuses fewer), `config.shards` what every rank ran and its own
+time, `cpu_baseline` the reference's CPU leg from rank 0 with `parity_vs_gpu` = EVERY rank's outputs
+against the oracle, and `workloads` carries configs[3] / configs[4] STRONG-scaling (the same 304 / 549
+tensors sharded over the N ranks).
 
 Other workloads (not the driver's default; same JSON contract, one line):
   --workload flux        BASELINE configs[3]: the full FLUX.1-dev weight set (304 quantized tensors, Q4_K_M mix:
@@ -63,16 +67,96 @@ def global_manifest(pkg, qtype, pairs, world):
     return m
 
 
-def max_over_ranks(value, device):
-    """MAX of a python float over all ranks (identity when not distributed)."""
+def max_over_ranks(value, device, group=None):
+    """MAX of a python float over all ranks (identity when not distributed).  ``group``: the RCCL fence group when there is one
+    (device tensor), else the default group (gloo: host tensor)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    if dist.get_backend() == "gloo":                  # test rig only (GGQ_BENCH_BACKEND=gloo): host tensors
+    if dist.get_backend(group) == "gloo":
         device = torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class World:
+    """The process group as bench.py uses it: fences around the timed regions, MAX of the step time, and object gathers of what
+    every rank did (shard, per-rank time, parity verdict).  NOTHING of the data path goes through it.
+
+    Two groups over the same ranks: a gloo CONTROL group (always: it cannot fail for GPU reasons, so every rank can take the same
+    decision about the other one) and the RCCL group the timed regions are fenced through (backend "nccl" IS RCCL on ROCm).  If the
+    RCCL group cannot be created or its first all-reduce fails on ANY rank, every rank learns so over the control group and the
+    fences fall back to gloo -- the line then says so in ``world.backend`` instead of the run dying (Next #1e).
+    GGQ_BENCH_BACKEND=gloo is the TEST RIG: no RCCL attempt, and ranks may share a device (N ranks on the one GPU of a test box)."""
+
+    def __init__(self, rank, local_rank, size, device, launched):
+        self.rank, self.local_rank, self.size, self.device = rank, local_rank, size, device
+        self.active = launched
+        self.rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") == "gloo"
+        self.fence_group, self.backend = None, None
+        if not launched:
+            return
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+        if self.rig:
+            self.backend = "gloo (GGQ_BENCH_BACKEND=gloo test rig: no RCCL attempt, ranks may share a device)"
+            return
+        err, pg = None, None
+        try:
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=600), device_id=device)
+            t = torch.ones(1, device=device)
+            dist.all_reduce(t, group=pg)
+            torch.cuda.synchronize(device)
+            if int(t.item()) != size:
+                err = f"RCCL all-reduce over {size} ranks returned {t.item()}"
+        except Exception as e:                                      # RuntimeError / DistBackendError: report, do not die
+            err = f"{type(e).__name__}: {e}".replace("\n", " ")[:240]
+        errs = self.gather(err)
+        bad = [e for e in errs if e]
+        if bad:
+            self.backend = f"gloo (RCCL group failed on {len(bad)} of {size} ranks, fences fell back to gloo: {bad[0]})"
+        else:
+            self.fence_group, self.backend = pg, "nccl"
+
+    def fence(self):
+        """barrier + device synchronize on both sides (the bracket of every timed region)."""
+        torch.cuda.synchronize(self.device)
+        if self.active:
+            import torch.distributed as dist
+            dist.barrier(group=self.fence_group)
+        torch.cuda.synchronize(self.device)
+
+    def max(self, value):
+        return max_over_ranks(value, self.device, self.fence_group) if self.active else float(value)
+
+    def gather(self, obj):
+        """[obj of rank 0, ..., obj of rank N-1] on every rank (control group)."""
+        if not self.active:
+            return [obj]
+        import torch.distributed as dist
+        rows = [None] * self.size
+        dist.all_gather_object(rows, obj)
+        return rows
+
+    def wait_host(self):
+        """Host-side barrier on the control group (the waiting ranks sleep in a socket read instead of spinning a GPU kernel in an
+        RCCL barrier while rank 0 runs its CPU legs)."""
+        if self.active:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def cpu_threads(self):
+        """Host threads one rank's CHECKER may use: the ranks of a node check their outputs at the same time."""
+        return max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", self.size))))
+
+    def close(self):
+        if self.active:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 def device_blocks(pkg, qtype, n_blocks, device, seed):
@@ -261,41 +345,87 @@ def cpu_baseline_port(pkg, plan, qtype, budget_s):
             "parity_vs_gpu": "bit-exact" if parity else "MISMATCH"}
 
 
-def cpu_baselines(pkg, plan, qtypes, budget_s):
-    """(cpu_baseline, cpu_baseline_port): the reference's own torch-CPU path when its sources are present (north_star: "the
-    reference's CPU torch path timed on the same box's host cores in the same run"), the AVX2 port beside it.  Without the
-    reference (neither /root/reference nor a staged oracle/_ref) the port IS the baseline, labelled as such."""
-    ref = cpu_baseline_reference(pkg, plan, qtypes, budget_s * 0.5)
-    port = cpu_baseline_port(pkg, plan, qtypes[0], budget_s * 0.5) if len(set(qtypes[:8])) == 1 else None
-    # parity of the WHOLE launch, outside every timed region: every output tensor of the plan against the oracle (oracle/plan_check.py:
-    # whole tensors vs the AVX2 leg, that leg vs the soft-float checker on three windows per tensor); the reference's own dequantize()
-    # is the checker for the first tensors (cpu_baseline_reference above)
+def parity_all_ranks(plan, qtypes, W):
+    """EVERY rank checks EVERY output tensor of its OWN timed launch against the oracle, outside the timed regions
+    (oracle/plan_check.py: whole tensors vs the AVX2 leg, that leg vs the soft-float checker on three windows per tensor), with its
+    share of the host's threads; the verdicts are gathered, so the line of an N-GPU run states N ranks' parity, not rank 0's."""
     from oracle import plan_check
     t0 = time.perf_counter()
-    n, bad = plan_check.check_plan(plan._keep, qtypes, plan.outputs)
+    n, bad = plan_check.check_plan(plan._keep, qtypes, plan.outputs, threads=W.cpu_threads() if W.size > 1 else None)
+    return W.gather({"rank": W.rank, "tensors": n, "differ": len(bad), "first": [list(x) for x in bad[:3]], "seconds": round(time.perf_counter() - t0, 2)})
+
+
+def parity_statement(rows, first=None, with_reference=False):
+    """One string for `cpu_baseline.parity_vs_gpu`: the MIN over ranks of the per-rank verdicts (any differing tensor on any rank
+    -> MISMATCH) and of rank 0's first-tensor checks against the reference itself."""
+    n = sum(r["tensors"] for r in rows)
+    bad = [r for r in rows if r["differ"]]
+    if bad or (first is not None and first != "bit-exact"):
+        return (f"MISMATCH ({sum(r['differ'] for r in bad)} of {n} tensors differ from the oracle on ranks {[r['rank'] for r in bad]}: "
+                f"{bad[0]['first'] if bad else []}; rank 0 first-tensor check {first})")
+    per = [r["tensors"] for r in rows]
+    if len(rows) == 1:
+        where, whose, who = f"{n} tensors", "the", "the"
+    else:
+        where = (f"{len(rows)} x {per[0]} = {n}" if len(set(per)) == 1 else f"{' + '.join(map(str, per))} = {n}") + f" tensors on {len(rows)} ranks"
+        whose, who = "every rank's", "rank 0's"
+    return (f"bit-exact ({where}: every output of {whose} timed launch vs the oracle"
+            + (f", {who} first 2 also vs the reference's dequantize() on torch-CPU" if with_reference else "") + ")")
+
+
+def cpu_baselines(pkg, plan, qtypes, budget_s, W):
+    """(cpu_baseline, cpu_baseline_port) on rank 0, None elsewhere; EVERY rank takes part (its own parity check is gathered).
+    The reference's own torch-CPU path when its sources are present (north_star: "the reference's CPU torch path timed on the same
+    box's host cores in the same run"), the AVX2 port beside it.  Without the reference (neither /root/reference nor a staged
+    oracle/_ref) the port IS the baseline, labelled as such.  For N > 1 the CPU legs still run, on rank 0, on rank 0's first tensors,
+    while the other ranks wait at the next fence: the line of a multi-GPU run carries the same baseline and a parity verdict from
+    every rank."""
+    rows = parity_all_ranks(plan, qtypes, W)                    # collective: before the rank-0-only legs
+    if W.rank != 0:
+        W.wait_host()                                           # sleep on the control group while rank 0 times the CPU legs
+        return None, None
+    ref = cpu_baseline_reference(pkg, plan, qtypes, budget_s * 0.5)
+    port = cpu_baseline_port(pkg, plan, qtypes[0], budget_s * 0.5) if len(set(qtypes[:8])) == 1 else None
     head = ref if ref is not None else port
-    if head is not None:
-        ok = not bad and head.get("parity_vs_gpu") == "bit-exact"
-        head["parity_vs_gpu"] = (f"bit-exact ({n} tensors: every output of the timed launch vs the oracle"
-                                 + (", the first 2 also vs the reference's dequantize() on torch-CPU" if ref is not None else "") + ")") if ok else \
-            f"MISMATCH ({len(bad)} of {n} tensors differ from the oracle: {bad[:3]}; first-tensor check {head.get('parity_vs_gpu')})"
-        head["parity_check_s"] = round(time.perf_counter() - t0, 2)
+    if head is None:                                            # mixed-format set without the reference's sources: parity only
+        head = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "no CPU leg (mixed formats, reference sources absent): parity only"}
+        ref = head
+    head["parity_vs_gpu"] = parity_statement(rows, head.get("parity_vs_gpu"), with_reference=head.get("kind") == "reference")
+    head["parity_check_s"] = max(r["seconds"] for r in rows)
+    head["parity_by_rank"] = [{k: r[k] for k in ("rank", "tensors", "differ", "seconds")} for r in rows]
+    W.wait_host()
     return (ref, port) if ref is not None else (port, None)
 
 
-def run_flux(pkg, args, rank, world, device, fence, workload=None, cpu_seconds=None):
-    """configs[3] / configs[4]: a full weight set, mixed quant types, resident in HBM, sharded over ranks."""
+def shard_report(pkg, manifest, indices, plan, gpu_ms_step, W):
+    """What every rank ACTUALLY ran (gathered, not recomputed on rank 0): its tensor indices, bytes, kernels and its own GPU time per
+    step in the reported region -- plus the statement that the shards are disjoint and cover the tensor list."""
+    rows = W.gather({"rank": W.rank, "device": str(W.device), "indices": list(indices), "bytes": plan.bytes, "kernels": plan.kernels,
+                     "gpu_ms_per_step": round(gpu_ms_step, 5)})
+    flat = sorted(i for r in rows for i in r["indices"])
+    cover = "disjoint, complete" if flat == list(range(len(manifest))) else f"BROKEN ({len(flat)} indices for {len(manifest)} tensors)"
+    shards = [{"rank": r["rank"], "device": r["device"], "tensors": len(r["indices"]), "bytes": r["bytes"], "kernels_per_step": r["kernels"],
+               "gpu_ms_per_step": r["gpu_ms_per_step"], "GBps": round(r["bytes"] / (r["gpu_ms_per_step"] * 1e-3) / 1e9, 1)} for r in rows]
+    return shards, f"{cover} ({len(flat)} of {len(manifest)} tensors over {len(rows)} ranks)"
+
+
+def run_flux(pkg, args, W, workload=None, cpu_seconds=None):
+    """configs[3] / configs[4]: a full weight set, mixed quant types, resident in HBM, the TENSOR LIST sharded over the ranks
+    (strong scaling: the same 304 / 549 tensors whatever N is; no collective on the data path).  Collective: every rank calls it."""
     workload = workload or args.workload
     cpu_seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
+    rank, world, device = W.rank, W.size, W.device
     if workload == "sd35-t5":
         manifest, label = pkg.manifests.sd35_t5(args.mix), "BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors"
     else:
         manifest, label = pkg.manifests.flux_dev(args.mix), "BASELINE configs[3]: full FLUX.1-dev weight set"
-    mine = pkg.sharding.shard(manifest, rank, world)
+    indices = pkg.sharding.partition(manifest, world)[rank]
+    mine = [manifest[i] for i in indices]
     plan = build_pool(pkg, mine, device, seed0=7000 + 1000 * rank)
-    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, device, fence, args.regions)
+    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, W, args.regions)
     total_bytes = sum(pkg.sharding.tensor_cost(e) for e in manifest)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
+    shards, cover = shard_report(pkg, manifest, indices, plan, gpu_ms_step, W)
     result = None
     if rank == 0:
         achieved = plan.bytes / (gpu_ms_step * 1e-3) / 1e9
@@ -313,16 +443,19 @@ def run_flux(pkg, args, rank, world, device, fence, workload=None, cpu_seconds=N
                        "elements": sum(s[0] * s[1] for _, _, s in manifest), "bytes_per_step": total_bytes,
                        "kernels_per_step_rank0": plan.kernels, "imbalance": round(pkg.sharding.imbalance(manifest, world), 4),
                        "parallelism": f"tensor-list sharding x{world}, no collectives",
-                       "timed_regions_ms_per_step": regions, "reported": "median region"},
+                       "shards": shards, "shard_cover": cover,
+                       "timed_regions_ms_per_step": regions, "reported": "median region; ms_per_step = MAX over ranks"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "ggq::dequant_many<Fmt*, ...> (one launch per format present)",
                          "algorithmic_bytes_per_launch": plan.bytes, "avg_launch_ms": round(gpu_ms_step, 5),
-                         "host_wall_ms_per_step": round(wall_ms_step, 5)},
+                         "host_wall_ms_per_step": round(wall_ms_step, 5), "of": "rank 0's shard"},
             "cpu_baseline": None,
         }
-        if world == 1 and cpu_seconds > 0:
-            result["cpu_baseline"], port = cpu_baselines(pkg, plan, [q for _, q, _ in mine], cpu_seconds)
+    if cpu_seconds > 0:
+        base, port = cpu_baselines(pkg, plan, [q for _, q, _ in mine], cpu_seconds, W)
+        if rank == 0:
+            result["cpu_baseline"] = base
             if port is not None:
                 result["cpu_baseline_port"] = port
     plan.close()
@@ -427,21 +560,17 @@ def load_traffic(pkg, workload_key):
     return table[workload_key], f"{table.get('_provenance', 'profiles/pmc_traffic.json')}; library build {build_id}"
 
 
-def observed_world(device, rank, use_dist):
-    """What the process group really looks like, gathered from every rank -- so that an N-GPU line proves N ranks on N distinct
-    devices took part (Next #4): group size and backend as torch.distributed reports them, and per rank the device
-    index, name, uuid and PCI bus id."""
-    import torch.distributed as dist
-    props = torch.cuda.get_device_properties(device)
-    mine = {"rank": rank, "device": str(device), "name": props.name, "arch": getattr(props, "gcnArchName", None),
+def observed_world(W):
+    """What the process group really looks like, gathered from every rank -- so that an N-GPU line proves N ranks on N DISTINCT
+    devices took part: group size, the backend the timed regions were fenced through, and per rank the device index, name, uuid and
+    PCI bus id.  Collective (every rank calls it)."""
+    props = torch.cuda.get_device_properties(W.device)
+    mine = {"rank": W.rank, "device": str(W.device), "name": props.name, "arch": getattr(props, "gcnArchName", None),
             "uuid": str(getattr(props, "uuid", "")) or None, "pci_bus_id": getattr(props, "pci_bus_id", None),
             "total_memory_GB": round(props.total_memory / 1e9, 1), "pid": os.getpid()}
-    if not (use_dist and dist.is_initialized()):
-        return {"size": 1, "backend": None, "ranks": [mine], "distinct_devices": 1}
-    rows = [None] * dist.get_world_size()
-    dist.all_gather_object(rows, mine)
+    rows = W.gather(mine)
     ids = {(r["uuid"] or r["pci_bus_id"] or r["device"]) for r in rows}
-    return {"size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": rows, "distinct_devices": len(ids)}
+    return {"size": W.size, "backend": W.backend, "ranks": rows, "distinct_devices": len(ids)}
 
 
 def run_per_layer(pkg, args, device, fence):
@@ -616,7 +745,7 @@ def run_per_layer(pkg, args, device, fence):
     }
 
 
-def median_region(pkg, plan, args, device, fence, regions, steps=None, warmup=None):
+def median_region(pkg, plan, args, W, regions, steps=None, warmup=None):
     """`regions` timed regions of exactly K launches each (the first after W warm-up launches), every one bracketed by the
     fence on both sides and reduced with MAX over ranks; the reported step time is the MEDIAN region's.  Returns
     (ms_per_step of the median region [MAX over ranks], this rank's gpu ms per step in that region, wall ms per step, all regions)."""
@@ -624,8 +753,8 @@ def median_region(pkg, plan, args, device, fence, regions, steps=None, warmup=No
     warmup = args.warmup if warmup is None else warmup
     rows = []
     for r in range(regions):
-        gpu_ms, wall_ms = timed_steps(plan, steps, warmup if r == 0 else 0, device, fence)
-        rows.append((max_over_ranks(gpu_ms / steps, device), gpu_ms / steps, wall_ms / steps))
+        gpu_ms, wall_ms = timed_steps(plan, steps, warmup if r == 0 else 0, W.device, W.fence)
+        rows.append((W.max(gpu_ms / steps), gpu_ms / steps, wall_ms / steps))
     order = sorted(range(regions), key=lambda k: rows[k][0])
     med = rows[order[regions // 2]]
     return med[0], med[1], med[2], [round(r[0], 5) for r in rows]
@@ -660,46 +789,40 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # GGQ_BENCH_BACKEND=gloo (test rig): exercise the N > 1 code path on a box with fewer GPUs than ranks -- ranks share
-    # devices round-robin and fence through gloo.  The driver's runs use the default: RCCL, one rank per GPU.
-    backend = os.environ.get("GGQ_BENCH_BACKEND", "nccl")
+    # devices round-robin and fence through gloo.  The driver's runs use the default: RCCL fences, one rank per GPU.
+    rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") == "gloo"
     n_dev = torch.cuda.device_count()
-    if backend == "nccl" and local_rank >= n_dev:
+    if not rig and local_rank >= n_dev:
         sys.exit(f"LOCAL_RANK={local_rank} but only {n_dev} GPU(s) visible: one rank per GPU")
     device = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(device)
 
-    import torch.distributed as dist
     # launched by torch.distributed.run (RANK set) -> join the process group even for N=1, so the
     # 1-GPU run exercises the very same fence / MAX code the 2/4/8-GPU runs use
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # RCCL: fence + MAX only
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    def fence():
-        torch.cuda.synchronize(device)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(device)
+    W = World(rank, local_rank, world, device, launched=world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ))
 
     pkg = load_package()
     pkg._native.lib()                       # fail loudly if the HIP extension is missing
     qt = pkg.qtypes
     head_q = qt.Q[args.qtype]
-    world_info = observed_world(device, rank, use_dist)   # every rank takes part (all_gather_object); rank 0 reports it
+    world_info = observed_world(W)          # every rank takes part; rank 0 reports it
+    if world > 1 and not rig and world_info["distinct_devices"] < world:
+        # an N-GPU line must come from N devices: refuse to print a rate that N ranks time-sharing fewer GPUs produced
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but the ranks sit on {world_info['distinct_devices']} distinct device(s): "
+                  f"{[(r['rank'], r['device'], r['uuid'] or r['pci_bus_id']) for r in world_info['ranks']]}", file=sys.stderr, flush=True)
+        W.close()
+        sys.exit(3)
 
     if args.workload != "pool":
         if args.workload in ("flux", "sd35-t5"):
-            result = run_flux(pkg, args, rank, world, device, fence)
+            result = run_flux(pkg, args, W)
             if result is not None:
                 result["world"] = world_info
         elif args.workload == "per-layer":
             if world != 1:
                 sys.exit("--workload per-layer is a single-GPU measurement")
-            result = run_per_layer(pkg, args, device, fence)
+            result = run_per_layer(pkg, args, device, W.fence)
             result.update({"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                            "dtype": "f16", "data": "synthetic"})
         else:
@@ -708,19 +831,19 @@ def main():
             result = run_flux_gguf(pkg, args, device)
         if rank == 0:
             print(json.dumps(result), flush=True)
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
+        W.close()
         return
 
     manifest = global_manifest(pkg, head_q, args.pairs, world)
-    mine = pkg.sharding.shard(manifest, rank, world)
+    indices = pkg.sharding.partition(manifest, world)[rank]
+    mine = [manifest[i] for i in indices]
     plan = build_pool(pkg, mine, device, seed0=1000 * rank)
     bytes_rank = plan.bytes
     assert plan.kernels == 1
 
-    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, device, fence, args.regions)
-    total_bytes = bytes_rank * world                                       # identical pools on every rank
+    ms_per_step, gpu_ms_step, wall_ms_step, regions = median_region(pkg, plan, args, W, args.regions)
+    shards, cover = shard_report(pkg, manifest, indices, plan, gpu_ms_step, W)
+    total_bytes = sum(sh["bytes"] for sh in shards)                        # what the ranks really moved (identical pools: N x rank 0's)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
 
     result = None
@@ -739,7 +862,7 @@ def main():
             "config": {"workload": wl, "qtype": head_q.name, "elements_per_gpu": n_el, "bytes_per_step_per_gpu": bytes_rank,
                        "tensors_per_gpu": len(mine), "parallelism": f"tensor-list sharding x{world}, no collectives",
                        "pct_hbm_peak_per_gpu": round(100.0 * value / world / HBM_PEAK_GBS, 2),
-                       "timed_regions_ms_per_step": regions, "reported": f"median of {len(regions)} timed regions of {args.steps} steps",
+                       "timed_regions_ms_per_step": regions, "reported": f"median of {len(regions)} timed regions of {args.steps} steps; ms_per_step = MAX over ranks",
                        "library_build": pkg._native.lib().ggq_build_id().decode(),
                        # the three rates of SURVEY.md section 8d, per GPU (rank 0): packed in / dense out / both, over the same time
                        "rates_GBps": {"in": round(in_bytes / (gpu_ms_step * 1e-3) / 1e9, 1),
@@ -752,6 +875,9 @@ def main():
                          "avg_launch_ms": round(gpu_ms_step, 5), "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
                          "host_wall_ms_per_step": round(wall_ms_step, 5)},
         }
+        if world > 1:
+            result["config"]["shards"], result["config"]["shard_cover"] = shards, cover
+            result["roofline"]["of"] = "rank 0's GPU"
     plan_head = plan
 
     per_qtype = {}
@@ -763,7 +889,7 @@ def main():
                                      "regions_GBps": [round(bytes_rank / (r * 1e-3) / 1e9, 1) for r in regions]}
                 continue
             p = build_pool(pkg, pkg.manifests.flux_linear_pool(q, args.pairs), device, seed0=50_000 + 100 * int(q))
-            _, ms, _, regs = median_region(pkg, p, args, device, fence, args.regions, steps=steps_q, warmup=args.warmup)   # same fences, same median-of-regions as the headline
+            _, ms, _, regs = median_region(pkg, p, args, W, args.regions, steps=steps_q, warmup=args.warmup)   # same fences, same median-of-regions as the headline
             gbs = p.bytes / (ms * 1e-3) / 1e9
             per_qtype[q.name] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2),
                                  "regions_GBps": [round(p.bytes / (r * 1e-3) / 1e9, 1) for r in regs]}
@@ -785,7 +911,7 @@ def main():
                 if cd == torch.float16 and od == torch.float16:
                     continue
                 p = pkg.grouped.DequantPlan([(d, head_q, sh) for d, sh in zip(plan_head._keep, shapes)], out_dtype=od, dequant_dtype=cd)
-                _, ms, _, regs = median_region(pkg, p, args, device, fence, args.regions, steps=steps_m, warmup=args.warmup)
+                _, ms, _, regs = median_region(pkg, p, args, W, args.regions, steps=steps_m, warmup=args.warmup)
                 gbs = p.bytes / (ms * 1e-3) / 1e9
                 per_mode[f"{names[cd]}->{names[od]}"] = {"GB/s": round(gbs, 1), "pct_hbm_peak": round(100 * gbs / HBM_PEAK_GBS, 2),
                                                          "regions_GBps": [round(p.bytes / (r * 1e-3) / 1e9, 1) for r in regs]}
@@ -794,28 +920,35 @@ def main():
                 torch.cuda.empty_cache()
         result["per_mode"] = per_mode
 
+    # parity of EVERY rank's timed launch + the CPU legs on rank 0 (outside every timed region; the other ranks wait at the next fence)
     if rank == 0:
         result["cpu_baseline"] = None
-        if world == 1 and args.cpu_seconds > 0:
-            result["cpu_baseline"], port = cpu_baselines(pkg, plan_head, [head_q] * len(plan_head.outputs), args.cpu_seconds)
+    if args.cpu_seconds > 0:
+        base, port = cpu_baselines(pkg, plan_head, [head_q] * len(plan_head.outputs), args.cpu_seconds, W)
+        if rank == 0:
+            result["cpu_baseline"] = base
             if port is not None:
                 result["cpu_baseline_port"] = port
-            rg = reference_gpu_leg(pkg, plan_head, [head_q] * len(plan_head.outputs), device)
-            if rg is not None:
-                rg["hip_path_speedup"] = round(result["roofline"]["achieved"] / rg["value"], 1)
-                result["reference_on_this_gpu"] = rg
+            if world == 1:
+                rg = reference_gpu_leg(pkg, plan_head, [head_q] * len(plan_head.outputs), device)
+                if rg is not None:
+                    rg["hip_path_speedup"] = round(result["roofline"]["achieved"] / rg["value"], 1)
+                    result["reference_on_this_gpu"] = rg
     plan_head.close()
     del plan_head, plan
     torch.cuda.empty_cache()
-    if rank == 0:
-        if world == 1 and not args.no_workloads:
-            # BASELINE configs[3] and configs[4] measured in the SAME run (each is also a workload of its own: --workload flux /
-            # sd35-t5): the full weight sets, one mixed-format plan launch per step, with their own roofline and CPU legs
-            subs = {}
-            for wl_name in ("flux", "sd35-t5"):
-                sub = run_flux(pkg, args, 0, 1, device, lambda: torch.cuda.synchronize(device), workload=wl_name, cpu_seconds=min(args.cpu_seconds, 6.0))
-                subs[wl_name] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline")}
-                torch.cuda.empty_cache()
+    if not args.no_workloads:
+        # BASELINE configs[3] and configs[4] measured in the SAME run (each is also a workload of its own: --workload flux /
+        # sd35-t5): the full weight sets, one mixed-format plan launch per step, with their own roofline, parity and CPU legs.
+        # For N > 1 these are the STRONG-scaling lines -- the same 304 / 549 tensors sharded over the N ranks (configs[4] is exactly
+        # "SD3.5-large + T5-xxl sharded across N GPUs") -- and every rank takes part.
+        subs = {}
+        for wl_name in ("flux", "sd35-t5"):
+            sub = run_flux(pkg, args, W, workload=wl_name, cpu_seconds=min(args.cpu_seconds, 6.0))
+            if rank == 0:
+                subs[wl_name] = {k: sub[k] for k in ("value", "unit", "n_gpus", "scaling", "ms_per_step", "config", "roofline", "cpu_baseline")}
+            torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
             # ... the same FLUX set the way the node drives it: one dequantize_tensor() launch per layer, bf16 out (Next #2)
             subs["per_layer"] = run_per_layer(pkg, args, device, lambda: torch.cuda.synchronize(device))
             torch.cuda.empty_cache()
@@ -831,11 +964,13 @@ def main():
                 args.steps = steps
                 subs["flux-gguf"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+        elif rank == 0:
+            subs["per_layer"] = subs["flux-gguf"] = {"skipped": "single-GPU measurements: see the --gpus 1 line"}
+        if rank == 0:
             result["workloads"] = subs
+    if rank == 0:
         print(json.dumps(result), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    W.close()
 
 
 if __name__ == "__main__":

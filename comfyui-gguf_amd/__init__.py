@@ -7,6 +7,7 @@ fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
 
     dequant     the mirrored reference interface (HIP-backed; raises GGQUnsupported otherwise)
     install     patch an unmodified ComfyUI-GGUF checkout so its nodes run on this path
+    autoinstall the literal drop-in: this directory inside ComfyUI/custom_nodes/ finds ComfyUI-GGUF and calls install() on it
     grouped     DequantPlan: a whole weight set in one launch per quant type
     gguf_file   GGUF container reader (native parser) + file -> HBM streaming upload
     loader      gguf_sd_loader & co. (reference loader.py:16-141) without the `gguf` package
@@ -24,7 +25,23 @@ from . import qtypes, synth  # noqa: F401  (torch-free)
 from .qtypes import GGMLQuantizationType, GGML_QUANT_SIZES  # noqa: F401
 
 __version__ = "0.1.0"
-_LAZY = ("_native", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap", "lookahead")
+# A ComfyUI custom-node directory (reference __init__.py:1-9 is activated the same way): ComfyUI requires the mapping to exist; this
+# package adds NO nodes -- it accelerates the ones ComfyUI-GGUF registers ("Unet Loader (GGUF)" & co. keep working unchanged).
+NODE_CLASS_MAPPINGS = {}
+NODE_DISPLAY_NAME_MAPPINGS = {}
+_LAZY = ("_native", "autoinstall", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap", "lookahead")
+
+
+def _running_under_comfyui():
+    import os
+    import sys
+    flag = os.environ.get("GGQ_AUTO_INSTALL", "")
+    return flag not in ("0",) and (flag == "1" or "folder_paths" in sys.modules)      # ComfyUI imports folder_paths before any custom node
+
+
+if _running_under_comfyui():
+    from . import autoinstall as _auto
+    _auto.arm()
 
 
 def __getattr__(name):

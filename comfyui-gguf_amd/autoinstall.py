@@ -1,0 +1,81 @@
+"""The literal drop-in: this directory copied (or symlinked) into ``ComfyUI/custom_nodes/`` next to ``ComfyUI-GGUF``.
+
+ComfyUI imports every ``custom_nodes/*/__init__.py`` (the way the reference itself is activated, reference __init__.py:1-9).  When
+this package is imported that way, ``arm()`` finds the ComfyUI-GGUF package -- already imported, or imported later: both orders
+happen, ComfyUI walks ``custom_nodes`` in directory order -- and calls ``install(ref_dequant, ref_ops)`` on it (install.py; options
+from the ``GGQ_*`` environment variables described there).  ComfyUI-GGUF is recognised by what this path needs from it, not by its
+directory name: a package whose ``.ops`` defines ``GGMLOps`` and ``GGMLTensor`` and whose ``.dequant`` defines ``dequantize_tensor``
+and ``dequantize_functions`` (reference ops.py:44,213; dequant.py:15,287).  Nothing else of ComfyUI is touched; no node is added.
+"""
+import importlib.abc
+import logging
+import sys
+
+log = logging.getLogger("comfyui-gguf_amd")
+_state = {"armed": False, "installed": None}
+
+
+def _is_ref_ops(mod):
+    return all(hasattr(mod, a) for a in ("GGMLOps", "GGMLTensor", "GGMLLayer")) and "." in getattr(mod, "__name__", "")
+
+
+def _install_over(ops_mod):
+    """``ops_mod`` = the reference's ops module, fully executed (so its ``.dequant`` sibling exists).  Never raises into the
+    reference's import: a failure is logged with its traceback and the reference keeps its own torch path."""
+    if _state["installed"] is not None:
+        return
+    pkg = ops_mod.__name__.rsplit(".", 1)[0]
+    deq = sys.modules.get(pkg + ".dequant")
+    if deq is None or not hasattr(deq, "dequantize_tensor") or not hasattr(deq, "dequantize_functions"):
+        return
+    try:
+        from . import install as inst
+        inst.install(deq, ops_mod, sys.modules.get(pkg + ".loader"))
+        _state["installed"] = pkg
+        log.info("comfyui-gguf_amd: MI355X HIP dequant path installed over %s (dequantize, dequantize_tensor%s)", pkg, inst.describe(deq))
+    except Exception:                                      # noqa: BLE001 -- see docstring
+        log.exception("comfyui-gguf_amd: could not install over %s; the reference's torch path stays in place", pkg)
+
+
+class _AfterOpsImport(importlib.abc.MetaPathFinder):
+    """One-shot post-import hook: lets the regular finders locate ``<package>.ops``, then runs ``_install_over`` right after the
+    module body has executed (its loader's ``exec_module`` is wrapped on that one spec).  Removes itself once it has installed."""
+
+    def find_spec(self, fullname, path, target=None):
+        if not fullname.endswith(".ops") or _state["installed"] is not None:
+            return None
+        for finder in sys.meta_path:
+            spec = finder.find_spec(fullname, path, target) if finder is not self and hasattr(finder, "find_spec") else None
+            if spec is not None:
+                break
+        else:
+            return None
+        loader = spec.loader
+        if loader is not None and hasattr(loader, "exec_module"):
+            run = loader.exec_module
+
+            def exec_module(module):
+                run(module)
+                if _is_ref_ops(module):
+                    _install_over(module)
+                    if _state["installed"] is not None and self in sys.meta_path:
+                        sys.meta_path.remove(self)
+            loader.exec_module = exec_module
+        return spec
+
+
+def arm():
+    """Install now if ComfyUI-GGUF is already imported, else as soon as it is.  Raises (in THIS package's import, where ComfyUI
+    reports it against this directory) if the HIP library is missing: there is no fallback to fall back to."""
+    if _state["armed"]:
+        return _state["installed"]
+    from . import _native
+    _native.lib()
+    _state["armed"] = True
+    for mod in list(sys.modules.values()):
+        if mod is not None and getattr(mod, "__name__", "").endswith(".ops") and _is_ref_ops(mod):
+            _install_over(mod)
+            if _state["installed"] is not None:
+                return _state["installed"]
+    sys.meta_path.insert(0, _AfterOpsImport())
+    return None

@@ -147,25 +147,18 @@ constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-mo
 // and still gain 1-2 % from it on single layers (rocprof kernel times, 3072x3072: 7.33 vs 7.45 us, 3072x12288: 17.36 vs 17.66 us).
 constexpr uint64_t XRUN_MIN_ELEMENTS_COOP = 1ull << 23;
 
-// Measurement knobs (environment, read once; not user settings): GGQ_XRUN_LOG2 forces the run length of the XCD mapping
-// for every format and size (0 = identity mapping everywhere), GGQ_LDS_PAD the occupancy-capping LDS pad.
-int env_int(const char* name, int lo, int hi)
-{
-    const char* e = getenv(name);
-    if (!e || !*e) return -1;
-    const int x = atoi(e);
-    return (x >= lo && x <= hi) ? x : -1;
-}
+// Measurement knobs of LAB builds only (ggq_host.hpp lab_int; the shipped library reads no environment): GGQ_XRUN_LOG2 forces the run
+// length of the XCD mapping for every format and size (0 = identity mapping everywhere), GGQ_LDS_PAD the occupancy-capping LDS pad.
 
 template <class F> uint32_t lds_pad_for()
 {
-    static const int o = env_int("GGQ_LDS_PAD", 0, 64 * 1024);
+    static const int o = lab_int("GGQ_LDS_PAD", 0, 64 * 1024);
     return o >= 0 ? (uint32_t)o : PadOf<F>::V;
 }
 
 template <class T, class F> uint32_t xrun_of(uint64_t groups)      // T = the team shape being launched
 {
-    static const int o = env_int("GGQ_XRUN_LOG2", 0, 16);
+    static const int o = lab_int("GGQ_XRUN_LOG2", 0, 16);
     if (o >= 0) return (uint32_t)o;
     return groups * (uint64_t)(T::G * F::BS) >= (T::COOP ? XRUN_MIN_ELEMENTS_COOP : XRUN_MIN_ELEMENTS) ? T::XRUN_LOG2 : 0u;
 }
@@ -192,10 +185,10 @@ template <> struct SoloWhenSmall<FmtQ8_0> { static constexpr bool V = true; };
 // path per step 5.0 ms with non-temporal stores, 2.2 ms with plain stores, 1.7-2.0 ms with sc1 -- and standalone (nothing reads the result) the sc1
 // launch is within 3 % of the non-temporal one where the plain one is 8-38 % slower (3072x3072 Q4_K -> bf16: 5.25 / 5.1 / 7.15 us;
 // profiles/r03_layer_store_cache_policy.json, r03_flux_forward_emulation_store_policy.json).  Both instantiations ship: ggq_dequant stores sc1 (its caller
-// is a layer), ggq_dequant_stream non-temporal (results nobody reads back soon).  GGQ_LAYER_NT_STORES=1 (environment) makes ggq_dequant stream too (A/B).
+// is a layer), ggq_dequant_stream non-temporal (results nobody reads back soon).  In lab builds (-DGGQ_LAB) GGQ_LAYER_NT_STORES=1 makes ggq_dequant stream too (A/B).
 bool layer_nt_default()
 {
-    static const int o = env_int("GGQ_LAYER_NT_STORES", 0, 1);
+    static const int o = lab_int("GGQ_LAYER_NT_STORES", 0, 1);
     return o == 1;
 }
 
@@ -337,6 +330,16 @@ struct Segment {
 };
 
 }  // namespace
+
+#ifdef GGQ_LAB
+int ggq::lab_int(const char* name, int lo, int hi)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return -1;
+    const int x = atoi(e);
+    return (x >= lo && x <= hi) ? x : -1;
+}
+#endif
 
 int ggq::hip_fail(hipError_t e)
 {

@@ -8,4 +8,13 @@ namespace ggq {
 // remember `e` for ggq_last_hip_error() on the calling thread; returns GGQ_ERR_HIP
 int hip_fail(hipError_t e);
 
+// Measurement knobs.  The SHIPPED library reads no environment variable: launch geometry is a function of the arguments only.  Lab builds
+// (tools/build_variant.py -DGGQ_LAB ...) compile the lookup in, so that one variant library can be A/B-ed over a knob on one box:
+// lab_int(name, lo, hi) = the integer value of environment variable `name` if set and within [lo, hi], else -1 (always -1 when shipped).
+#ifdef GGQ_LAB
+int lab_int(const char* name, int lo, int hi);
+#else
+constexpr int lab_int(const char*, int, int) { return -1; }
+#endif
+
 }  // namespace ggq

@@ -48,10 +48,8 @@ hipError_t launch(const void* packed, const void* x, const void* bias, void* y, 
     const uint32_t need = (rows + LIN_WAVES - 1) / LIN_WAVES;
     uint32_t per_cu = (152u * 1024u) / lds;             // workgroups whose LDS fits one CU (160 KiB, some left to the allocator's granularity) ...
     per_cu = per_cu > 8u ? 8u : (per_cu < 1u ? 1u : per_cu);   // ... up to the 32 wave slots of a CU at <= 64 VGPRs
-    if (const char* e = std::getenv("GGQ_LIN_PER_CU")) {       // A/B runs
-        const int v = std::atoi(e);
-        if (v >= 1 && (uint32_t)v < per_cu) per_cu = (uint32_t)v;
-    }
+    static const int lab_per_cu = lab_int("GGQ_LIN_PER_CU", 1, 8);   // lab builds only, read once (-1 in the shipped library)
+    if (lab_per_cu >= 1 && (uint32_t)lab_per_cu < per_cu) per_cu = (uint32_t)lab_per_cu;
     const uint32_t grid = need < cus * per_cu ? need : cus * per_cu;
     if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
         static std::atomic<uint64_t> raised{0};
@@ -118,14 +116,10 @@ hipError_t launch_tile_wm(const void* packed, const void* x, const void* bias, v
 template <class F, int OUT>
 hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
-    static const int wm = [] {
-        const char* e = getenv("GGQ_TILE_WM");
-        return (e && *e == '4') ? 4 : ((e && *e == '2') ? 2 : GGQ_TILE_WM_DEFAULT);
-    }();
-#ifdef GGQ_TILE_WM_AB      /* A/B builds carry both shapes; the shipped library only the default one */
-    if (wm != GGQ_TILE_WM_DEFAULT) return launch_tile_wm<F, OUT, (GGQ_TILE_WM_DEFAULT == 4 ? 2 : 4)>(packed, x, bias, y, m, rows, cols, s);
+#ifdef GGQ_TILE_WM_AB      /* A/B builds (with -DGGQ_LAB) carry both shapes; the shipped library only the default one */
+    static const int wm = lab_int("GGQ_TILE_WM", 2, 4);
+    if ((wm == 2 || wm == 4) && wm != GGQ_TILE_WM_DEFAULT) return launch_tile_wm<F, OUT, (GGQ_TILE_WM_DEFAULT == 4 ? 2 : 4)>(packed, x, bias, y, m, rows, cols, s);
 #endif
-    (void)wm;
     return launch_tile_wm<F, OUT, GGQ_TILE_WM_DEFAULT>(packed, x, bias, y, m, rows, cols, s);
 }
 
@@ -136,7 +130,7 @@ hipError_t launch_tile_any(const void* packed, const void* x, const void* bias, 
 {
 #ifdef GGQ_WITH_TILE64
     if constexpr (Step64<F>::OK) {
-        static const bool enabled = [] { const char* e = getenv("GGQ_TILE64"); return !(e && *e == '0'); }();
+        static const bool enabled = lab_int("GGQ_TILE64", 0, 1) != 0;
         if (enabled) {
             constexpr uint32_t lds = (uint32_t)Gemm64Geom<F>::LDS_BYTES;
             static_assert(lds <= 160 * 1024, "one workgroup's LDS");
@@ -169,15 +163,11 @@ const MfmaEntry MFMA[] = {
     GGQ_MF(FmtIQ4_NL), GGQ_MF(FmtIQ4_XS),
 };
 
-// rows of x from which the shared-tile kernel takes over (measurement knob GGQ_TILE_MIN_M, read once)
+// rows of x from which the shared-tile kernel takes over (lab builds: knob GGQ_TILE_MIN_M, read once)
 uint32_t tile_min_m()
 {
-    static const uint32_t v = [] {
-        const char* e = getenv("GGQ_TILE_MIN_M");
-        const int x = (e && *e) ? atoi(e) : 0;
-        return x > 0 ? (uint32_t)x : 192u;
-    }();
-    return v;
+    static const int v = lab_int("GGQ_TILE_MIN_M", 1, 1 << 20);
+    return v > 0 ? (uint32_t)v : 192u;
 }
 
 }  // namespace

@@ -114,17 +114,16 @@ def _device_served(index):
     return ok
 
 
-def _launch(qtype, data, n_blocks, out, compute_code, out_code):
-    """Enqueue on torch's CURRENT stream of data's device: orders after the H2D copy, before F.linear."""
-    if _ggq_dequant is None:
-        _bind()
+def _launch(qtype, data, n_blocks, out, compute_code, out_code, entry=None):
+    """Enqueue on torch's CURRENT stream of data's device: orders after the H2D copy, before F.linear.
+    ``entry``: the C entry point to call (None = ggq_dequant through the fastest binding there is)."""
     index = data.device.index
     if not (_DEVICE_OK.get(index) or _device_served(index)):
         raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
     if _cur_device() != index:
         with torch.cuda.device(index):
-            return _launch(qtype, data, n_blocks, out, compute_code, out_code)
-    rc = _ggq_dequant(qtype, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, out_code, _raw_stream(index))
+            return _launch(qtype, data, n_blocks, out, compute_code, out_code, entry)
+    rc = (entry or _ggq_dequant or _bind())(qtype, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, out_code, _raw_stream(index))
     if rc:
         _native.check(rc, f"ggq_dequant({Q(int(qtype)).name})")
 
@@ -177,7 +176,7 @@ def _is_compiling():
 _HIP_TABLE = {k: (int(k),) + tuple(GGML_QUANT_SIZES[k]) for k in HIP_QTYPES}
 
 
-def _dequant_hip(data, qtype, out_dtype, compute=None, oshape=None):
+def _dequant_hip(data, qtype, out_dtype, compute=None, oshape=None, entry=None):
     """Packed device bytes -> dense tensor of ``out_dtype``: the block function's op sequence in the
     ``compute`` dtype (None = fp16), then one cast to ``out_dtype``, in one kernel.  Result is flat, or
     of ``oshape`` when given (must hold exactly the dequantized elements, as the reference's reshape)."""
@@ -207,7 +206,7 @@ def _dequant_hip(data, qtype, out_dtype, compute=None, oshape=None):
             if out.numel() != n:
                 raise RuntimeError(f"shape '{list(oshape)}' is invalid for input of size {n}")   # what .reshape(oshape) raises
         if n_blocks:
-            _launch(qid, data, n_blocks, out, compute_code, out_code)
+            _launch(qid, data, n_blocks, out, compute_code, out_code, entry)
     return out
 
 
@@ -225,8 +224,9 @@ def dequantize(data, qtype, oshape, dtype=None):
     return _dequant_hip(data, qtype, _COMPUTE_TORCH[dtype], compute=dtype, oshape=oshape)
 
 
-def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
-    """dequant.py:15-28, same argument meaning and result."""
+def dequantize_tensor(tensor, dtype=None, dequant_dtype=None, _entry=None):
+    """dequant.py:15-28, same argument meaning and result.  (``_entry``, private: another C entry point with ggq_dequant's
+    signature for the launch -- how dequantize_tensor_streaming asks for non-temporal stores without touching any shared state.)"""
     qtype = getattr(tensor, "tensor_type", None)
     try:
         ent = _HIP_TABLE.get(qtype)
@@ -259,31 +259,24 @@ def dequantize_tensor(tensor, dtype=None, dequant_dtype=None):
                     if not (_DEVICE_OK.get(index) or _device_served(index)):
                         raise GGQUnsupported(f"cuda:{index} is not a gfx950 device")
                     if _cur_device() != index:
-                        _launch(qid, data, n_blocks, out, compute_code, _OUT_CODE[dtype])
+                        _launch(qid, data, n_blocks, out, compute_code, _OUT_CODE[dtype], _entry)
                     else:
-                        rc = (_ggq_dequant or _bind())(qid, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, _OUT_CODE[dtype], _raw_stream(index))
+                        rc = (_entry or _ggq_dequant or _bind())(qid, data.data_ptr(), n_blocks, out.data_ptr(), compute_code, _OUT_CODE[dtype], _raw_stream(index))
                         if rc:
                             _native.check(rc, f"ggq_dequant({Q(qid).name})")
             return out
-    return _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype)
+    return _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype, _entry)
 
 
 def dequantize_tensor_streaming(tensor, dtype=None, dequant_dtype=None):
     """``dequantize_tensor`` for a result that is NOT read back soon (a tensor unpacked at load time, a measurement of the unpack
     alone): same kernels and values, non-temporal stores (include/ggq.h ``ggq_dequant_stream``).  The per-layer path stores write-through (sc1),
-    because the layer's GEMM reads the weight next and finds it in cache.  Not for concurrent use with dequantize_tensor from another
-    thread (it swaps the module's launch binding for the duration of the call)."""
-    global _ggq_dequant
-    if _ggq_dequant is None:
-        _bind()
-    keep, _ggq_dequant = _ggq_dequant, _native.lib().ggq_dequant_stream
-    try:
-        return dequantize_tensor(tensor, dtype, dequant_dtype)
-    finally:
-        _ggq_dequant = keep
+    because the layer's GEMM reads the weight next and finds it in cache.  Re-entrant and thread-safe: the entry point travels down the
+    call as an argument, no module state changes."""
+    return dequantize_tensor(tensor, dtype, dequant_dtype, _native.lib().ggq_dequant_stream)
 
 
-def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype):
+def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype, entry=None):
     """dequant.py:15-28 for everything the hot path above does not take: passthrough types, plain-int qtypes, result dtypes the
     kernels do not emit, carriers that are not tensors, BF16, tracing under torch.compile, unknown qtypes."""
     oshape = getattr(tensor, "tensor_shape", None)
@@ -301,8 +294,8 @@ def _dequantize_tensor_general(tensor, dtype, dequant_dtype, qtype):
         data = tensor if isinstance(tensor, torch.Tensor) else tensor.data
         if dtype in _OUT_CODE:
             # dequantize(..., dtype=dequant_dtype).to(dtype) with the cast fused into the kernel's store
-            return _dequant_hip(data, key, dtype, compute=dequant_dtype, oshape=oshape)
-        return _dequant_hip(data, key, _COMPUTE_TORCH[dequant_dtype], compute=dequant_dtype, oshape=oshape).to(dtype)
+            return _dequant_hip(data, key, dtype, compute=dequant_dtype, oshape=oshape, entry=entry)
+        return _dequant_hip(data, key, _COMPUTE_TORCH[dequant_dtype], compute=dequant_dtype, oshape=oshape, entry=entry).to(dtype)
     if key == Q.BF16:
         return dequantize(tensor.data, key, oshape, dtype=dequant_dtype).to(dtype)
     raise GGQUnsupported(f"no HIP unpacker for qtype {getattr(qtype, 'name', qtype)!r} "

@@ -126,6 +126,8 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         if ref_ops is None:
             raise ValueError("fused_small_m / fused_mfma patch GGMLOps.Linear: pass ref_ops")
         patched.append(_fuse_linear(ref_ops.GGMLOps.Linear, unsupported, bool(fused_small_m), fused_mfma_max_m if fused_mfma else 0))
+    elif ref_ops is not None and hasattr(getattr(ref_ops, "GGMLOps", None), "Linear"):
+        patched.append(_recommend_small_m(ref_ops.GGMLOps.Linear))
     if gather_embedding is None:
         gather_embedding = os.environ.get("GGQ_GATHER_EMBEDDING", "0") not in ("", "0")
     if gather_embedding:
@@ -142,8 +144,50 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
         from .overlap import attach
         record, prefetcher = attach(ref_ops.GGMLLayer, resident=(overlap == "all"))
         patched.append(record)
-    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher, "ahead": ahead}
+    options = {"dense_cache_gb": dense_cache_gb or None, "fused_small_m": bool(fused_small_m) or None, "fused_mfma": (fused_mfma_max_m if fused_mfma else None),
+               "gather_embedding": bool(gather_embedding) or None, "overlap": overlap or None, "cpu_route_mb": cpu_route_mb or None,
+               "lookahead": lookahead if ahead is not None else None}
+    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher, "ahead": ahead,
+                                   "options": {k: v for k, v in options.items() if v is not None}}
     return orig
+
+
+def describe(ref_dequant):
+    """'; options: ...' of an installation, for the one log line the drop-in prints (autoinstall.py)."""
+    rec = _installed.get(id(ref_dequant)) or {}
+    names = sorted({f"{getattr(o, '__name__', o)}.{n}" for o, n, _ in rec.get("patched", [])} - {"dequantize", "dequantize_tensor"})
+    opts = ", ".join(f"{k}={v}" for k, v in rec.get("options", {}).items()) or "defaults: bit-exact unpack + F.linear"
+    return f"; patched {', '.join(names)}; {opts}"
+
+
+_SMALL_M_HINT = ("comfyui-gguf_amd: this model runs quantized linears on inputs of <= 4 rows (modulation layers): each call unpacks the whole weight for a "
+                 "GEMV (about 3 ms per FLUX.1-dev step).  GGQ_FUSED_SMALL_M=1 (install(fused_small_m=True)) fuses them -- results equal to F.linear "
+                 "up to fp32 summation order instead of bit for bit, which is why it is not the default.")
+
+
+def _recommend_small_m(linear_cls, probe_calls=4096):
+    """Default installs only: a pass-through wrapper of ``linear_cls.forward_ggml_cast_weights`` that logs ``_SMALL_M_HINT`` ONCE, the
+    first time a quantized weight of >= 1 M elements meets an input of <= 4 rows, and then takes itself out again (also after
+    ``probe_calls`` calls without such a layer): zero cost from then on.  Returns the record uninstall() restores."""
+    import logging
+    reference_forward = linear_cls.forward_ggml_cast_weights
+    left = [probe_calls]
+
+    def forward_ggml_cast_weights(self, input):
+        if _hip._is_compiling():                                 # torch.compile traces the reference's method only
+            return reference_forward(self, input)
+        left[0] -= 1
+        cols = input.shape[-1]
+        hit = cols and input.numel() // cols <= 4 and hasattr(self.weight, "tensor_type") and self.weight.numel() >= (1 << 20) and input.is_cuda
+        if hit:
+            logging.getLogger("comfyui-gguf_amd").warning(_SMALL_M_HINT)
+        if (hit or left[0] <= 0) and linear_cls.forward_ggml_cast_weights is forward_ggml_cast_weights:
+            linear_cls.forward_ggml_cast_weights = reference_forward
+        return reference_forward(self, input)
+
+    forward_ggml_cast_weights.__wrapped__ = reference_forward
+    linear_cls.forward_ggml_cast_weights = forward_ggml_cast_weights
+    return (linear_cls, "forward_ggml_cast_weights", reference_forward)
 
 
 def scratch_bytes(ref_dequant):

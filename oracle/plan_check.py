@@ -18,15 +18,15 @@ from . import cast_f16_to_bf16_bits, dequant_f16, geometry, simd_available
 _WINDOW_BLOCKS = {32: 4096, 256: 512}       # 131072 elements per window
 
 
-def check_tensor(packed_dev, qtype, out_dev, windows=True):
+def check_tensor(packed_dev, qtype, out_dev, windows=True, threads=None):
     """None if ``out_dev`` (fp16 / bf16 / fp32 tensor on the GPU) is what the reference computes from ``packed_dev``, else a
-    short description of the first difference."""
+    short description of the first difference.  ``threads``: OpenMP team of the AVX2 leg (several ranks of one node check at once)."""
     import torch
     bs, ts = geometry(qtype)
     host = packed_dev.reshape(-1).cpu().numpy()
     n_blocks = host.size // ts
     simd = simd_available()
-    want = dequant_f16(qtype, host, simd=simd).view(np.uint16)
+    want = dequant_f16(qtype, host, simd=simd, threads=threads).view(np.uint16)
     spots = []
     if windows and n_blocks:
         w = min(_WINDOW_BLOCKS[bs], n_blocks)
@@ -56,11 +56,11 @@ def check_tensor(packed_dev, qtype, out_dev, windows=True):
     return None
 
 
-def check_plan(packed, qtypes, outputs, windows=True):
+def check_plan(packed, qtypes, outputs, windows=True, threads=None):
     """(tensors checked, [(index, description) of every tensor that differs])."""
     bad = []
     for i, (p, q, o) in enumerate(zip(packed, qtypes, outputs)):
-        msg = check_tensor(p, q, o, windows=windows)
+        msg = check_tensor(p, q, o, windows=windows, threads=threads)
         if msg is not None:
             bad.append((i, msg))
     return len(outputs), bad

@@ -1,0 +1,126 @@
+"""The literal drop-in (Next #6): this package's directory inside ``ComfyUI/custom_nodes/`` next to ComfyUI-GGUF.
+A fake ``custom_nodes`` tree is imported the way ComfyUI's ``load_custom_node`` imports it (by path, module name = the path, the
+directory order deciding who comes first) -- in BOTH orders -- and afterwards the reference's modules must be running on install()'s
+wrappers.  The reference's dequant.py / ops.py are the real files (copied into the temporary tree at test time), over the fake
+``comfy`` of oracle/fake_comfy.py.  CPU only: the wrappers hand CPU tensors to the reference's own functions."""
+import importlib.util
+import logging
+import os
+import shutil
+import sys
+import types
+
+import pytest
+import torch
+
+from oracle import fake_comfy, reference
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not reference.available(), reason="reference sources not present")
+
+
+def _comfy_load_custom_node(module_path):
+    """ComfyUI nodes.py load_custom_node, reduced to what matters here: import by path, require NODE_CLASS_MAPPINGS."""
+    name = module_path.replace(".", "_x_")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(module_path, "__init__.py"))
+    module = importlib.util.module_from_spec(spec)
+    sys.modules[name] = module
+    spec.loader.exec_module(module)
+    assert hasattr(module, "NODE_CLASS_MAPPINGS"), f"ComfyUI would skip {module_path}: no NODE_CLASS_MAPPINGS"
+    return module
+
+
+@pytest.fixture
+def custom_nodes(tmp_path, monkeypatch):
+    reference.ensure_gguf()
+    for k, v in fake_comfy.build().items():
+        monkeypatch.setitem(sys.modules, k, v)
+    monkeypatch.setitem(sys.modules, "folder_paths", types.ModuleType("folder_paths"))      # what ComfyUI has imported before any custom node
+    monkeypatch.delenv("GGQ_AUTO_INSTALL", raising=False)
+    root = tmp_path / "ComfyUI" / "custom_nodes"
+    ref = root / "ComfyUI-GGUF"
+    ref.mkdir(parents=True)
+    for f in ("dequant.py", "ops.py"):
+        shutil.copy(os.path.join(reference.REFERENCE_DIR, f), ref / f)
+    # the reference's __init__.py imports its nodes (which need all of ComfyUI); what reaches this path is `from .ops import GGMLOps` (nodes.py:15)
+    (ref / "__init__.py").write_text("from .ops import GGMLOps\nNODE_CLASS_MAPPINGS = {'UnetLoaderGGUF': object}\n")
+    os.symlink(os.path.join(ROOT, "comfyui-gguf_amd"), root / "comfyui-gguf_amd")
+    before, meta = set(sys.modules), list(sys.meta_path)
+    yield str(ref), str(root / "comfyui-gguf_amd")
+    sys.meta_path[:] = meta
+    for k in set(sys.modules) - before:
+        del sys.modules[k]
+
+
+def _assert_installed(ref_mod, amd_mod):
+    rd, ro = sys.modules[ref_mod.__name__ + ".dequant"], sys.modules[ref_mod.__name__ + ".ops"]
+    assert amd_mod.NODE_CLASS_MAPPINGS == {} and amd_mod.autoinstall._state["installed"] == ref_mod.__name__
+    assert hasattr(rd.dequantize_tensor, "__wrapped__") and hasattr(rd.dequantize, "__wrapped__")
+    assert ro.dequantize_tensor is rd.dequantize_tensor                       # the name ops.py bound at import time (ops.py:9)
+    assert not any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)   # the hook took itself out
+    # CPU-resident weights still run the reference's own code through the wrappers
+    Q = amd_mod.qtypes.Q
+    blocks = amd_mod.synth.make_blocks(Q.Q4_K, 8 * 2, seed=3)
+    w = ro.GGMLTensor(torch.from_numpy(blocks.reshape(-1).copy()), tensor_type=Q.Q4_K, tensor_shape=torch.Size((8, 512)))
+    assert torch.equal(rd.dequantize_tensor(w, torch.float32), rd.dequantize_tensor.__wrapped__(w, torch.float32))
+    amd_mod.install.uninstall(rd)
+    assert not hasattr(rd.dequantize_tensor, "__wrapped__")
+
+
+def test_reference_first_then_this_package(custom_nodes, caplog):
+    ref_dir, amd_dir = custom_nodes
+    with caplog.at_level(logging.INFO, logger="comfyui-gguf_amd"):
+        ref_mod = _comfy_load_custom_node(ref_dir)                # "ComfyUI-GGUF" sorts before "comfyui-gguf_amd": ComfyUI's usual order
+        amd_mod = _comfy_load_custom_node(amd_dir)
+    _assert_installed(ref_mod, amd_mod)
+    assert sum("HIP dequant path installed over" in r.getMessage() for r in caplog.records) == 1      # one line, saying what was patched
+    assert "dequantize_tensor" in caplog.text and "defaults" in caplog.text
+
+
+def test_this_package_first_then_reference(custom_nodes):
+    ref_dir, amd_dir = custom_nodes
+    amd_mod = _comfy_load_custom_node(amd_dir)
+    assert amd_mod.autoinstall._state == {"armed": True, "installed": None}
+    assert any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)
+    import json                                                   # unrelated imports pass through the armed hook untouched
+    assert json.loads("1") == 1
+    ref_mod = _comfy_load_custom_node(ref_dir)
+    _assert_installed(ref_mod, amd_mod)
+
+
+def test_not_armed_outside_comfyui(custom_nodes, monkeypatch):
+    """Imported by anything else (tests, bench.py, a script), the package patches nothing and installs no import hook."""
+    ref_dir, amd_dir = custom_nodes
+    monkeypatch.delitem(sys.modules, "folder_paths")
+    amd_mod = _comfy_load_custom_node(amd_dir)
+    ref_mod = _comfy_load_custom_node(ref_dir)
+    assert "autoinstall" not in amd_mod.__dict__ and not any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)
+    assert not hasattr(sys.modules[ref_mod.__name__ + ".dequant"].dequantize_tensor, "__wrapped__")
+
+
+def test_small_m_recommendation_is_logged_once_and_removes_itself(custom_nodes, caplog):
+    """Default installs watch GGMLOps.Linear for one-to-four-row inputs on big quantized weights, say ONCE that GGQ_FUSED_SMALL_M=1
+    would fuse them, and take the watcher out again."""
+    ref_dir, amd_dir = custom_nodes
+    ref_mod = _comfy_load_custom_node(ref_dir)
+    amd_mod = _comfy_load_custom_node(amd_dir)
+    ro = sys.modules[ref_mod.__name__ + ".ops"]
+    Linear = ro.GGMLOps.Linear
+    watcher = Linear.forward_ggml_cast_weights
+    assert hasattr(watcher, "__wrapped__")
+    Q = amd_mod.qtypes.Q
+    w = ro.GGMLTensor(torch.from_numpy(amd_mod.synth.make_tensor_bytes(Q.Q8_0, (1024, 1024), seed=5).copy()), tensor_type=Q.Q8_0, tensor_shape=torch.Size((1024, 1024)))
+    lin = Linear(1024, 1024)
+    lin.weight, lin.bias = torch.nn.Parameter(w, requires_grad=False), None
+
+    class OnGpu(torch.Tensor):                                     # a CPU tensor that says it is a GPU one: the watcher only looks, the reference computes
+        is_cuda = True
+
+    x = torch.randn(1, 1024)
+    with caplog.at_level(logging.WARNING, logger="comfyui-gguf_amd"):
+        y = lin(x.as_subclass(OnGpu))
+        assert Linear.forward_ggml_cast_weights is watcher.__wrapped__           # took itself out after the hit
+        lin(x.as_subclass(OnGpu))
+    assert sum("GGQ_FUSED_SMALL_M=1" in r.getMessage() for r in caplog.records) == 1
+    assert torch.equal(torch.Tensor(y), lin(x))
+    amd_mod.install.uninstall(sys.modules[ref_mod.__name__ + ".dequant"])

@@ -38,9 +38,9 @@ def _run(nproc, script_args, timeout=600):
     return proc
 
 
-def _bench(nproc, extra):
-    args = ["bench.py", "--gpus", str(nproc), "--steps", "6", "--warmup", "2", "--regions", "3", "--no-per-qtype", "--no-per-mode", "--cpu-seconds", "0",
-            "--no-workloads"] + extra
+def _bench(nproc, extra, cpu_seconds=0, workloads=False):
+    args = ["bench.py", "--gpus", str(nproc), "--steps", "6", "--warmup", "2", "--regions", "3", "--no-per-qtype", "--no-per-mode", "--cpu-seconds", str(cpu_seconds)]
+    args += ([] if workloads else ["--no-workloads"]) + extra
     if nproc == 1:
         proc = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert proc.returncode == 0, proc.stderr[-3000:]
@@ -80,6 +80,72 @@ def test_bench_sharded_weight_set_two_ranks_on_one_gpu(pkg):
     parts = pkg.sharding.partition(manifest, 2)
     assert sorted(i for p in parts for i in p) == list(range(len(manifest)))
     assert 0.75 <= two["value"] / one["value"] <= 1.15, (one["value"], two["value"])
+
+
+def _self_proving(line, ranks, tensors_per_rank=None, total=None):
+    """What an N-rank line must carry to count as measured (Next #1): N ranks observed, what each ran, parity from
+    EVERY rank, a non-null CPU baseline."""
+    w = line["world"]
+    assert w["size"] == ranks and len(w["ranks"]) == ranks and sorted(r["rank"] for r in w["ranks"]) == list(range(ranks))
+    assert w["backend"].startswith("gloo") and "test rig" in w["backend"]          # this box has one GPU: the rig, and the line says so
+    assert len({r["pid"] for r in w["ranks"]}) == ranks                              # real processes
+    shards = line["config"]["shards"]
+    assert [s["rank"] for s in shards] == list(range(ranks)) and all(s["tensors"] > 0 and s["gpu_ms_per_step"] > 0 for s in shards)
+    assert line["config"]["shard_cover"].startswith("disjoint, complete")
+    if total is not None:
+        assert sum(s["tensors"] for s in shards) == total
+    # ms_per_step is the MAX over ranks of the reported region
+    assert line["ms_per_step"] >= max(s["gpu_ms_per_step"] for s in shards) * 0.999
+    cb = line["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["kind"] in ("reference", "port") and cb["cores"] >= 1
+    assert cb["parity_vs_gpu"].startswith("bit-exact") and f"on {ranks} ranks" in cb["parity_vs_gpu"], cb["parity_vs_gpu"]
+    by = cb["parity_by_rank"]
+    assert [r["rank"] for r in by] == list(range(ranks)) and all(r["differ"] == 0 and r["tensors"] > 0 for r in by)
+    assert [r["tensors"] for r in by] == [s["tensors"] for s in shards]            # every rank checked exactly what it ran
+    if tensors_per_rank is not None:
+        assert all(r["tensors"] == tensors_per_rank for r in by)
+
+
+@pytest.mark.timeout(2400)
+def test_bench_eight_ranks_default_line_is_self_proving(pkg):
+    """`bench.py --gpus 8` the way the driver launches it -- 8 processes, here time-sharing the box's one GPU under the gloo rig: the
+    weak-scaling headline AND the configs[3] / configs[4] strong-scaling sub-lines, every one with per-rank parity and a CPU baseline."""
+    line = _bench(8, ["--pairs", "4"], cpu_seconds=4, workloads=True)
+    assert all(k in line for k in CONTRACT) and line["n_gpus"] == 8 and line["scaling"] == "weak"
+    _self_proving(line, 8, tensors_per_rank=8, total=64)
+    for name, n_tensors in (("flux", 304), ("sd35-t5", 549)):
+        sub = line["workloads"][name]
+        assert sub["scaling"] == "strong" and sub["n_gpus"] == 8
+        sub["world"] = line["world"]
+        _self_proving(sub, 8, total=n_tensors)
+        assert 1.0 <= sub["config"]["imbalance"] < 1.01
+        manifest = getattr(pkg.manifests, "flux_dev" if name == "flux" else "sd35_t5")("Q4_K_M")
+        assert sub["config"]["bytes_per_step"] == sum(pkg.sharding.tensor_cost(e) for e in manifest)
+        assert sum(s["bytes"] for s in sub["config"]["shards"]) == sub["config"]["bytes_per_step"]
+    assert "skipped" in line["workloads"]["per_layer"]
+
+
+@pytest.mark.timeout(1800)
+def test_bench_sd35_t5_eight_ranks_on_one_gpu():
+    """`--workload sd35-t5 --gpus 8` = BASELINE configs[4] as a line of its own."""
+    line = _bench(8, ["--workload", "sd35-t5"], cpu_seconds=4)
+    assert all(k in line for k in CONTRACT) and line["n_gpus"] == 8 and line["scaling"] == "strong"
+    _self_proving(line, 8, total=549)
+
+
+@pytest.mark.timeout(600)
+def test_bench_refuses_n_ranks_on_fewer_devices():
+    """Without the rig an N-GPU line must come from N devices: 2 ranks on this 1-GPU box are refused before anything is timed."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("GGQ_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "2"]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
+    assert proc.returncode != 0
+    assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]          # no rate printed
+    assert "one rank per GPU" in proc.stderr or "distinct device" in proc.stderr
 
 
 @pytest.mark.timeout(600)

@@ -655,3 +655,18 @@ def test_k_exhaustive_generators_cover_what_they_say(pkg):
     for ib in range(8):
         run = b[0, 8 + 16 * ib:8 + 16 * ib + 16]
         assert sorted(set((run & 15).tolist())) == list(range(16)) and sorted(set((run >> 4).tolist())) == list(range(16))
+
+
+def test_shipped_library_reads_no_environment(pkg):
+    """Measurement knobs (GGQ_XRUN_LOG2, GGQ_LDS_PAD, GGQ_TILE_MIN_M, ...) exist only in lab builds (-DGGQ_LAB, tools/build_variant.py): the
+    shipped library holds no GGQ_* string at all (`strings libggq_hip.so | grep GGQ_` is empty) and does not import getenv."""
+    path = pkg._native.LIB_PATH
+    if os.environ.get("GGQ_HIP_LIB"):
+        pytest.skip("a variant library is loaded")
+    with open(path, "rb") as f:
+        blob = f.read()
+    assert b"GGQ_" not in blob
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout
