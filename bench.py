@@ -462,6 +462,80 @@ def run_flux(pkg, args, W, workload=None, cpu_seconds=None):
     return result
 
 
+def run_inproc(pkg, args, device):
+    """--inproc-gpus N: ONE process drives N GPUs (ComfyUI is single-process) -- the tensor list of the workload partitioned with the same
+    sharding.partition, one DequantPlan per device (grouped.ShardedPlan), every launch enqueued by this one host thread, no collective.
+    A step = one launch on every device; timed with a HIP event pair per device stream AND the host clock around the K steps
+    (`ms_per_step` = the slowest device's; `host_wall_ms_per_step` shows whether one thread keeps N devices fed).  Under the test rig
+    (GGQ_BENCH_BACKEND=gloo) the N shards may share devices -- then they time-share and the line says so."""
+    n = args.inproc_gpus
+    n_dev = torch.cuda.device_count()
+    rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") == "gloo"
+    if n > n_dev and not rig:
+        sys.exit(f"--inproc-gpus {n} but only {n_dev} GPU(s) visible")
+    devices = [torch.device("cuda", i % n_dev) for i in range(n)]
+    if args.workload == "sd35-t5":
+        manifest, label = pkg.manifests.sd35_t5(args.mix), "BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors"
+    elif args.workload == "flux":
+        manifest, label = pkg.manifests.flux_dev(args.mix), "BASELINE configs[3]: full FLUX.1-dev weight set"
+    else:
+        manifest, label = global_manifest(pkg, pkg.qtypes.Q[args.qtype], args.pairs, n), f"BASELINE configs[2] {args.qtype} pool x {n}"
+    rows = pkg.grouped.ShardedPlan.assignment(manifest, devices)
+    shards = []
+    for r, (d, ix) in enumerate(rows):
+        shards.append((d, [(device_blocks(pkg, manifest[i][1], pkg.synth.n_blocks_for(manifest[i][1], manifest[i][2][0] * manifest[i][2][1]), d, 7000 + 1000 * r + k),
+                            manifest[i][1], manifest[i][2]) for k, i in enumerate(ix)]))
+    plan = pkg.grouped.ShardedPlan(shards, own_streams=True, indices=[ix for _, ix in rows])
+
+    def sync_all():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    regions = []
+    for r in range(args.regions):
+        for _ in range(args.warmup if r == 0 else 0):
+            plan.launch()
+        sync_all()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan.plans]
+        t0 = time.perf_counter()
+        for (a, _), st in zip(evs, plan.streams):
+            a.record(st)
+        for _ in range(args.steps):
+            plan.launch()
+        for (_, b), st in zip(evs, plan.streams):
+            b.record(st)
+        t_enq = time.perf_counter() - t0
+        sync_all()
+        wall = time.perf_counter() - t0
+        per = [a.elapsed_time(b) / args.steps for a, b in evs]
+        regions.append((max(per), per, wall * 1e3 / args.steps, t_enq * 1e3 / args.steps))
+    regions.sort(key=lambda x: x[0])
+    ms, per, wall_ms, enq_ms = regions[len(regions) // 2]
+    from oracle import plan_check
+    bad, checked = [], 0
+    for (d, items), p in zip(shards, plan.plans):
+        k, b = plan_check.check_plan([it[0] for it in items], [it[1] for it in items], p.outputs)
+        checked, bad = checked + k, bad + b
+    total = sum(pkg.sharding.tensor_cost(e) for e in manifest)
+    result = {
+        "metric": "dequant GB/s (packed in -> fp16 out), (in+out) bytes / time", "value": round(total / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+        "scaling": "strong" if args.workload != "pool" else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"{label} ({len(manifest)} tensors), HBM-resident, sharded over {n} device(s) driven by ONE process / ONE host thread",
+                   "parallelism": f"in-process tensor-list sharding x{n} (grouped.ShardedPlan), no collectives, no peer access",
+                   "devices": [str(d) for d in devices], "distinct_devices": len(set(devices)), "bytes_per_step": total,
+                   "shards": [{"device": str(d), "tensors": len(items), "bytes": p.bytes, "gpu_ms_per_step": round(t, 5)} for (d, items), p, t in zip(shards, plan.plans, per)],
+                   "imbalance": round(pkg.sharding.imbalance(manifest, n), 4), "host_wall_ms_per_step": round(wall_ms, 5),
+                   "host_enqueue_ms_per_step": round(enq_ms, 5), "timed_regions_ms_per_step": [round(x[0], 5) for x in regions]},
+        "roofline": {"bound": "hbm", "achieved": round(plan.plans[0].bytes / (per[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(plan.plans[0].bytes / (per[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "of": f"shard 0 on {devices[0]}"},
+        "cpu_baseline": {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": "no CPU timing leg on this line (see the default line); parity only",
+                         "parity_vs_gpu": f"bit-exact ({checked} tensors on {len(plan.plans)} shards: every output vs the oracle)" if not bad else f"MISMATCH {bad[:3]}"},
+    }
+    plan.close()
+    return result
+
+
 def run_flux_gguf(pkg, args, device):
     """File -> HBM -> dense: write the FLUX.1-dev weight set as a synthetic .gguf, then time the native
     parse, the streaming upload (pread -> pinned -> H2D) and the dequant of everything that landed."""
@@ -776,11 +850,21 @@ def main():
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
     ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf / per-layer: only the first N tensors (smoke runs, tests)")
+    ap.add_argument("--inproc-gpus", type=int, default=0, help="ONE process driving N GPUs (grouped.ShardedPlan) instead of one process per GPU; with --workload pool|flux|sd35-t5")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.inproc_gpus:
+        if world != 1 or args.gpus != 1 or args.workload not in ("pool", "flux", "sd35-t5"):
+            sys.exit("--inproc-gpus N is a single-process run (no torch.distributed launch, --gpus 1) of --workload pool, flux or sd35-t5")
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        pkg = load_package()
+        pkg._native.lib()
+        print(json.dumps(run_inproc(pkg, args, torch.device("cuda", 0))), flush=True)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "

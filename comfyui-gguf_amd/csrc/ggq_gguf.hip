@@ -174,12 +174,13 @@ int parse(ggq_gguf* g)
     auto it = g->kv_index.find("general.alignment");
     if (it != g->kv_index.end()) {
         const KV& kv = g->kvs[(size_t)it->second];
-        if (kv.type == GGQ_KV_UINT32) {
-            uint32_t a;
-            std::memcpy(&a, g->map + kv.off, 4);
-            if (a == 0 || (a & (a - 1)) != 0) return GGQ_ERR_FORMAT;
-            g->alignment = a;
-        }
+        // "general.alignment: uint32 ... must be a multiple of 8" (GGUF specification); gguf-py refuses any other value type too
+        // ("Bad type for general.alignment field")
+        if (kv.type != GGQ_KV_UINT32) return GGQ_ERR_FORMAT;
+        uint32_t a;
+        std::memcpy(&a, g->map + kv.off, 4);
+        if (a == 0 || a % 8u != 0) return GGQ_ERR_FORMAT;
+        g->alignment = a;
     }
     g->tensors.reserve(n_tensors);
     for (uint64_t i = 0; i < n_tensors; i++) {

@@ -4,6 +4,11 @@
 and for roofline measurement over a working set far beyond the 256 MiB Infinity Cache, the
 tensors are described once -- device pointers, block counts -- and each ``launch()`` enqueues one
 kernel per (quant type, output dtype) present, with no per-launch host->device traffic.
+
+``ShardedPlan`` is the same thing over SEVERAL GPUs from ONE process (ComfyUI is single-process): the tensor list is partitioned
+with ``sharding.partition`` -- the very split the one-process-per-GPU runs use -- one ``DequantPlan`` per device, every launch
+enqueued by the calling thread (launches are asynchronous: at ~1 ms of GPU work per launch one thread keeps eight devices fed).
+No collective, no peer access, no cross-device ordering: every tensor is independent.
 """
 import ctypes
 
@@ -85,3 +90,82 @@ class DequantPlan:
             self.close()
         except Exception:
             pass
+
+
+class ShardedPlan:
+    """One ``DequantPlan`` per shard, shards on several devices (or, for tests on a one-GPU box, several shards on one device).
+
+    ``shards``: list of (device, items) -- items as for ``DequantPlan``, already resident on that device.  Use
+    :meth:`place` to get there from a flat tensor list.  ``own_streams=True`` gives every shard a stream of its own (ordered after
+    its device's current stream at every launch); the default enqueues on each device's CURRENT stream, like ``DequantPlan``.
+    """
+
+    def __init__(self, shards, out_dtype=torch.float16, dequant_dtype=None, own_streams=False, indices=None):
+        shards = [(torch.device(d), list(items)) for d, items in shards]
+        if not shards or any(not items for _, items in shards):
+            raise ValueError("every shard needs at least one tensor")
+        self.devices = [d for d, _ in shards]
+        self.plans = [DequantPlan(items, out_dtype=out_dtype, dequant_dtype=dequant_dtype) for _, items in shards]
+        for d, p in zip(self.devices, self.plans):
+            if p.device != d:
+                raise ValueError(f"shard declared on {d} holds tensors on {p.device}")
+        self.streams = [torch.cuda.Stream(d) for d in self.devices] if own_streams else None
+        self.indices = indices                      # indices[s][k] = position of shard s's k-th tensor in the flat list (place())
+        self.bytes = sum(p.bytes for p in self.plans)
+        self.kernels = sum(p.kernels for p in self.plans)
+
+    @staticmethod
+    def assignment(entries, devices):
+        """[(device, [indices into entries])] -- ``sharding.partition`` over ``len(devices)`` shards, shard r on ``devices[r]``; shards
+        that got nothing (fewer tensors than devices) drop out.  ``entries``: (anything, qtype, shape) triples.  Pure: no GPU needed."""
+        from .sharding import partition
+        devices = [torch.device(d) for d in devices]
+        if not devices:
+            raise ValueError("no devices")
+        parts = partition([(None, e[1], e[2]) for e in entries], len(devices))
+        return [(d, p) for d, p in zip(devices, parts) if p]
+
+    @classmethod
+    def place(cls, items, devices, out_dtype=torch.float16, dequant_dtype=None, own_streams=None):
+        """Partition a flat list of (packed, qtype, shape) over ``devices`` (sharding.partition: LPT on read+write bytes) and move
+        every tensor's packed bytes to its device (no copy when it is already there).  ``devices`` may name one device several times."""
+        items = [tuple(it) for it in items]
+        used = cls.assignment(items, devices)
+        shards = [(d, [(_as_bytes(items[i][0]).to(d, non_blocking=True),) + items[i][1:] for i in p]) for d, p in used]
+        if own_streams is None:
+            own_streams = len({d for d, _ in used}) < len(used)              # several shards on one device: only separate streams overlap them
+        return cls(shards, out_dtype=out_dtype, dequant_dtype=dequant_dtype, own_streams=own_streams, indices=[p for _, p in used])
+
+    @property
+    def outputs(self):
+        """Dense tensors per shard; see :meth:`outputs_in_order` for the flat list's order."""
+        return [p.outputs for p in self.plans]
+
+    def outputs_in_order(self):
+        """The dense tensors in the order of the flat list given to :meth:`place` (each on its shard's device)."""
+        if self.indices is None:
+            raise ValueError("only a plan built by place() knows the flat order")
+        flat = [None] * sum(len(ix) for ix in self.indices)
+        for ix, p in zip(self.indices, self.plans):
+            for i, o in zip(ix, p.outputs):
+                flat[i] = o
+        return flat
+
+    def launch(self):
+        """Enqueue every shard's kernels from the calling thread; returns at once (nothing is synchronised)."""
+        for k, p in enumerate(self.plans):
+            if self.streams is None:
+                p.launch()
+            else:
+                s = self.streams[k]
+                s.wait_stream(torch.cuda.current_stream(p.device))
+                p.launch(s)
+        return self.outputs
+
+    def synchronize(self):
+        for k, p in enumerate(self.plans):
+            (self.streams[k] if self.streams is not None else torch.cuda.current_stream(p.device)).synchronize()
+
+    def close(self):
+        for p in self.plans:
+            p.close()

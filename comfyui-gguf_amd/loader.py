@@ -131,7 +131,7 @@ def _logical_shape(reader, tensor, arch, compat):
 
 
 def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=False, is_text_model=False, *,
-                   device=None, detect_arch=None, upload_threads=0, shard=None):
+                   device=None, detect_arch=None, upload_threads=0, shard=None, devices=None):
     """Read a GGUF file as a state dict of ``GGMLTensor`` (loader.py:51-141).
 
     ``device=None`` (the reference's behaviour): every tensor is a read-only mmap view on the CPU.
@@ -141,7 +141,28 @@ def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=Fal
     ``shard=(rank, world_size)`` (with ``device``): one process per GPU, no collectives -- only the tensors
     ``sharding.partition`` assigns to ``rank`` (every rank computes the same assignment from the file's tensor table alone)
     are uploaded and returned.
+    ``devices=["cuda:0", "cuda:1", ...]``: ONE process, several GPUs (ComfyUI is single-process) -- the same partition, shard r
+    uploaded to ``devices[r]``, ONE state dict whose tensors live on different devices (``state_dict_plan`` then returns a
+    ``grouped.ShardedPlan``).  No peer access, no collective.
     """
+    if devices is not None:
+        if device is not None or shard is not None:
+            raise ValueError("devices=[...] places the shards itself: do not pass device= or shard=")
+        devices = list(devices)
+        if not devices:
+            raise ValueError("devices=[...] is empty")
+        merged, arch = {}, None
+        for r, dev in enumerate(devices):
+            part, arch = gguf_sd_loader(path, handle_prefix, True, is_text_model, device=dev, detect_arch=detect_arch,
+                                        upload_threads=upload_threads, shard=(r, len(devices)))
+            for v in part.values():
+                if getattr(v, "is_largest_weight", False):
+                    del v.is_largest_weight                   # per-shard marks: re-marked over the whole dict below
+            merged.update(part)
+        quantized = [key for key, value in merged.items() if is_quantized(value)]
+        if quantized:
+            merged[max(quantized, key=lambda key: merged[key].numel())].is_largest_weight = True
+        return (merged, arch) if return_arch else merged
     with GGUFFile(path) as reader:
         selected = _select(reader, handle_prefix)
         arch, compat = _architecture(reader, path, [key for key, _ in selected], is_text_model, detect_arch)
@@ -197,4 +218,12 @@ def state_dict_plan(state_dict, dtype=torch.float16, dequant_dtype=None):
     if not keys:
         raise ValueError("no GPU-resident quantized tensors with a HIP unpacker in this state dict")
     items = [(state_dict[k].as_subclass(torch.Tensor), state_dict[k].tensor_type, tuple(state_dict[k].tensor_shape)) for k in keys]
+    on = {}
+    for k, it in zip(keys, items):
+        on.setdefault(it[0].device, []).append((k, it))
+    if len(on) > 1:
+        # loaded with devices=[...]: one plan per device, keys regrouped device by device (plan.outputs[s][i] <-> keys[s][i])
+        from .grouped import ShardedPlan
+        return (ShardedPlan([(d, [it for _, it in rows]) for d, rows in on.items()], out_dtype=dtype, dequant_dtype=dequant_dtype),
+                [[k for k, _ in rows] for rows in on.values()])
     return DequantPlan(items, out_dtype=dtype, dequant_dtype=dequant_dtype), keys

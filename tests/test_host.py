@@ -670,3 +670,27 @@ def test_shipped_library_reads_no_environment(pkg):
     nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
     if nm.returncode == 0:
         assert "getenv" not in nm.stdout
+
+
+def test_in_process_multi_device_placement(pkg):
+    """grouped.ShardedPlan.assignment: the split of ONE process over several GPUs is the very partition the one-process-per-GPU runs
+    use (sharding.partition), shard r on devices[r] -- disjoint, complete, balanced; devices may repeat; empty shards drop out."""
+    SP = pkg.grouped.ShardedPlan
+    manifest = pkg.manifests.sd35_t5("Q4_K_M")
+    devices = [f"cuda:{i}" for i in range(8)]
+    rows = SP.assignment(manifest, devices)
+    assert [str(d) for d, _ in rows] == devices
+    assert [ix for _, ix in rows] == pkg.sharding.partition(manifest, 8)
+    assert sorted(i for _, ix in rows for i in ix) == list(range(len(manifest)))
+    loads = [sum(pkg.sharding.tensor_cost(manifest[i]) for i in ix) for _, ix in rows]
+    assert max(loads) / (sum(loads) / 8) < 1.01
+    two = SP.assignment(manifest, ["cuda:0", "cuda:0"])                      # a one-GPU test box: two shards on one device
+    assert [str(d) for d, _ in two] == ["cuda:0", "cuda:0"] and [ix for _, ix in two] == pkg.sharding.partition(manifest, 2)
+    few = SP.assignment(manifest[:3], devices)                              # 3 tensors, 8 devices: 3 shards
+    assert len(few) == 3 and sorted(i for _, ix in few for i in ix) == [0, 1, 2]
+    with pytest.raises(ValueError):
+        SP.assignment(manifest, [])
+    with pytest.raises(ValueError):
+        pkg.loader.gguf_sd_loader("nope.gguf", devices=["cuda:0"], device="cuda:0")
+    with pytest.raises(ValueError):
+        pkg.loader.gguf_sd_loader("nope.gguf", devices=[])
