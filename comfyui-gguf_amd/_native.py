@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 # GGQ_HIP_LIB: load another build of the library (A/B measurements); default = the in-tree build
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
-HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_gemm64.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
+HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
 ABI_VERSION = 9
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately

@@ -492,26 +492,38 @@ typedef GGQ_GLOBAL uint8_t* gptr;
 // policy: written through to memory and dropped from the XCD's L2, yet still found in the Infinity Cache by the GEMM that reads the weight next.
 // Measured against plain, sc0, sc0 sc1 and non-temporal stores on one box (profiles/r03_layer_store_cache_policy.json): standalone 3072x3072 Q4_K ->
 // bf16 5.25 us (nt 5.1, plain 7.15), cost of the dequant path per emulated FLUX step 1.7-2.0 ms (plain 2.2, nt 5.0).  GGQ_PLAIN_STORE_POLICY
-// (A/B builds): 0 = plain, 2 = sc1 (shipped), 3 = sc0 sc1, 6 = sc0.  hipcc has no builtin for a 16-byte sc1 store, hence the asm statement; it is
-// the last thing a team does before its waves retire, so no later access depends on the compiler counting it.
+// (A/B builds): 0 = plain, 2 = sc1 (shipped), 3 = sc0 sc1, 6 = sc0.
+//
+// hipcc has no cache-policy argument on a plain global store, but it has one on the raw BUFFER store builtin, and that one the compiler MODELS
+// (data-register hazards, vmcnt): rounds 2-3 issued these stores as an inline-asm `global_store_dwordx4 ... sc1` + a hand-placed `s_nop 1`,
+// whose correctness rested on the exact wait-state count of one architecture.  Now: a Window = a buffer resource over the
+// bytes a team is about to write (base wave-uniform, 32-bit per-lane offsets -- one VGPR of address instead of two), and
+// `buffer_store_dwordx4 v[data], v_off, s[rsrc], 0 offen sc1` from `__builtin_amdgcn_raw_buffer_store_b128(..., aux)`; aux bits on gfx94x/gfx950:
+// 1 = sc0, 2 = nt, 16 = sc1.  No asm statement is left in the store path.
 #ifndef GGQ_PLAIN_STORE_POLICY
 #define GGQ_PLAIN_STORE_POLICY 2
 #endif
+constexpr int STORE_AUX = GGQ_PLAIN_STORE_POLICY == 2 ? 16 : (GGQ_PLAIN_STORE_POLICY == 3 ? 17 : (GGQ_PLAIN_STORE_POLICY == 6 ? 1 : 0));
+
 template <bool NT, class T>
 GGQ_DEV void gstore(gptr p, T v)
 {
-    if constexpr (NT) {
-        __builtin_nontemporal_store(v, (GGQ_GLOBAL T*)p);
-    } else if constexpr (GGQ_PLAIN_STORE_POLICY == 0 || sizeof(T) != 16) {
-        *(GGQ_GLOBAL T*)p = v;
-    } else {
-        const u32x4 u = __builtin_bit_cast(u32x4, v);
-        // (the s_nop 1 INSIDE the statement: hipcc does not model an asm store, and its next instruction could overwrite the data registers
-        // before the store has read them -- cdna_hip_programming.md section 5.7 item 1; without it a few 16-byte pieces per tensor come out wrong)
-        if constexpr (GGQ_PLAIN_STORE_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
-        else if constexpr (GGQ_PLAIN_STORE_POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(u) : "memory");
-    }
+    if constexpr (NT) __builtin_nontemporal_store(v, (GGQ_GLOBAL T*)p);
+    else *(GGQ_GLOBAL T*)p = v;
+}
+
+// `bytes` of output starting at the WAVE-UNIFORM address `base` (stores outside [0, bytes) are dropped by the hardware's range check; the
+// callers mask them anyway).  word 3 = 0x00020000: raw buffer, 32-bit data format (what every dwordx4 buffer access on gfx9 uses).
+struct Window { __amdgpu_buffer_rsrc_t rsrc; };
+GGQ_DEV Window window(gptr base, uint32_t bytes)
+{
+    return Window{__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)base, (short)0, (int)bytes, 0x00020000)};
+}
+template <class T>
+GGQ_DEV void wstore(const Window& w, uint32_t byte_off, T v)
+{
+    static_assert(sizeof(T) == 16, "16-byte stores");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w.rsrc, (int)byte_off, 0, STORE_AUX);
 }
 
 template <bool NT>
@@ -533,9 +545,10 @@ GGQ_DEV uint32_t h2_to_bf16x2(uint32_t hh) { const h2 v = as_h2(hh); return pack
 //                   same chunk and each keeps one half                        PIECES = 2
 template <int OUT> struct Layout { static constexpr int PIECES = (OUT == OUT_F32) ? 2 : 1, ELEMS = 8 / PIECES; };
 
-// decode -> arithmetic (ARITH) -> cast (OUT) -> one 16-byte store; `piece` selects the quad for fp32 output
-template <class F, int ARITH, int OUT, bool NT>
-GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
+// decode -> arithmetic (ARITH) -> cast (OUT) -> one 16-byte value handed to `store` (a non-temporal global store, or a Window store with the
+// write-through policy: the caller knows where); `piece` selects the quad for fp32 output
+template <class F, int ARITH, int OUT, class Store>
+GGQ_DEV void emit_to(const Fields& f, int piece, Store&& store)
 {
     constexpr int KIND = F::KIND, BIAS = F::BIAS;
     constexpr bool RB = ARITH == AR_BF16;
@@ -544,14 +557,14 @@ GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
         if constexpr (ARITH == AR_F16) {
             const u32x2 v = quad_f16<KIND, BIAS>(f, t);
             const h2 a = as_h2(v.x), b = as_h2(v.y);
-            gstore<NT>(out + elem * 4, f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
+            store(f32x4{(float)a.x, (float)a.y, (float)b.x, (float)b.y});
         } else {
-            gstore<NT>(out + elem * 4, rnd4<RB>(quad_f32<KIND, BIAS, RB>(f, t)));
+            store(rnd4<RB>(quad_f32<KIND, BIAS, RB>(f, t)));
         }
     } else if constexpr (ARITH == AR_F16) {
         const u32x2 lo = quad_f16<KIND, BIAS>(f, f.t0), hi = quad_f16<KIND, BIAS>(f, f.t1);
-        if constexpr (OUT == OUT_F16) gstore<NT>(out + elem * 2, u32x4{lo.x, lo.y, hi.x, hi.y});
-        else gstore<NT>(out + elem * 2, u32x4{h2_to_bf16x2(lo.x), h2_to_bf16x2(lo.y), h2_to_bf16x2(hi.x), h2_to_bf16x2(hi.y)});
+        if constexpr (OUT == OUT_F16) store(u32x4{lo.x, lo.y, hi.x, hi.y});
+        else store(u32x4{h2_to_bf16x2(lo.x), h2_to_bf16x2(lo.y), h2_to_bf16x2(hi.x), h2_to_bf16x2(hi.y)});
     } else {
         f32x4 lo = quad_f32<KIND, BIAS, RB>(f, f.t0), hi = quad_f32<KIND, BIAS, RB>(f, f.t1);
         if constexpr (OUT == OUT_F16) {          // bf16 arithmetic, fp16 result: round to bf16 FIRST, then to fp16
@@ -559,9 +572,16 @@ GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
             hi = rnd4<RB>(hi);
         }
         // bf16 result: RNE of the fp32 op result == the op's own bf16 rounding (RB) or the cast of an fp32 value
-        if constexpr (OUT == OUT_BF16) gstore<NT>(out + elem * 2, u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)});
-        else gstore<NT>(out + elem * 2, u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)});
+        if constexpr (OUT == OUT_BF16) store(u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)});
+        else store(u32x4{pack_f16(lo.x, lo.y), pack_f16(lo.z, lo.w), pack_f16(hi.x, hi.y), pack_f16(hi.z, hi.w)});
     }
+}
+
+// ... to element `elem` of the dense tensor at `out`, through a 64-bit address (non-temporal when NT, else a plain store: the harnesses)
+template <class F, int ARITH, int OUT, bool NT>
+GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
+{
+    emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { gstore<NT>(out + elem * (uint64_t)OutBytes<OUT>::V, v); });
 }
 
 // ============================================================================ the engine
@@ -662,6 +682,9 @@ struct Engine {
         for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + TEAM * u) * 16) = pf[u];
         team_sync();
         const uint64_t b0 = w.lg * (uint64_t)G;
+        // write-through launches: a Window over this group's slice of the output (base wave-uniform; the per-lane part of the address is 32 bits)
+        constexpr uint32_t OB = (uint32_t)OutBytes<OUT>::V;
+        [[maybe_unused]] const Window win = window(w.out + b0 * (uint64_t)(BS * OB), (uint32_t)(G * BS) * OB);
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
             const int unit = lane + TEAM * s;
@@ -670,7 +693,8 @@ struct Engine {
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
                 const Fields f = F::template fields<true>(slice + a + bl * TS, j);
-                emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
+                if constexpr (NTS) emit<F, ARITH, OUT, true>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
+                else emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { wstore(win, (uint32_t)(bl * BS + j * 8 + piece * Layout<OUT>::ELEMS) * OB, v); });
             }
         }
     }

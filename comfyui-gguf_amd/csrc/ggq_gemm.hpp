@@ -11,10 +11,13 @@
 // ds_read_b128.  One decoded weight feeds 256 rows of x instead of 32..128.
 //
 // Shape of the work (16 waves = 1024 threads, four waves per SIMD, one workgroup per CU):
-//   * LDS: X[3] and W[2] tiles of 256 rows x 64 B (32 K-elements): 80 KiB; STAGING: the packed bytes of the tile's 256 weight rows for one
-//     span of K (one K-quant super-block = 256 elements; 4 blocks = 128 elements for the legacy formats), double-buffered where that fits
-//     (Q4_K 2 x 36 KiB) -- everything arrives by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass): packed spans one span
-//     ahead, x tiles two K-steps ahead, waited for with a COUNTED s_waitcnt vmcnt and a raw s_barrier;
+//   * LDS (GemmGeom below, per format): X[XR] and W[2] tiles of 256 rows x 64 B (32 K-elements) = 16 KiB each, plus STAGING = the packed bytes of the
+//     tile's 256 weight rows for one span of K (one K-quant super-block = 256 elements; 4 blocks = 128 elements for the legacy formats) rounded up to
+//     whole 16-byte units per thread: Q4_K (144 B per row-span -> 9 units) and Q8_0 (136 B, 2-byte aligned -> 10 units) 48 KiB, Q6_K (210 B -> 14) 64 KiB.
+//     Two staging buffers where 4 tiles + 2 x STAGING <= 160 KiB (Q4_K, Q8_0: exactly 160 KiB, XR = 2); one buffer, refilled at the span boundary,
+//     and a THIRD x tile otherwise (Q6_K: 5 x 16 + 64 = 144 KiB, XR = 3).  Everything arrives by LDS-DMA (global_load_lds_dwordx4: no staging
+//     registers, no ds_write pass): packed spans one span ahead, x tiles one (XR = 2) or two (XR = 3) K-steps ahead, waited for with a COUNTED
+//     s_waitcnt vmcnt and a raw s_barrier;
 //   * tile rows are 64 B; the 16-byte column is XOR-swizzled with ((row >> 3) & 3) ^ ((row >> 1) & 1) (for the DMA'd x tile on the SOURCE
 //     address, the LDS image of a DMA being lane-linear): ds_read_b128 fragment reads (one row per lane, gfx950's four non-contiguous 16-lane
 //     groups, MI355X_MICROARCH.md LDS) and the decode's ds_write_b128 (4 lanes per row) are bank-conflict-free;
@@ -27,9 +30,15 @@
 //   * workgroup -> tile mapping: XCD x (workgroup b runs on XCD b % 8) takes a contiguous eighth of the tiles in column-major
 //     order, so the tiles that run together in one XCD share weight panels (read from HBM once) and x panels in that XCD's L2.
 //
-// Where the time goes (EXPERIMENTS.md A2c): a K-step without the decode takes 1600 cycles, without the MFMAs 1400 (VALU-issue-bound: the price
-// of reproducing the reference's fp16 values), together 2100 -- VALU issue and the matrix pipe mostly in series; 0.82-0.85 PFLOP/s at 4608 rows,
-// behind unpack + hipBLASLt, hence opt-in and off the default path above ~256 rows.
+// Where the time goes, and why this kernel is FROZEN (round 4; EXPERIMENTS.md A2c / R4-2, profiles/r04_gemm_skeleton_sweep.json, r04_gemm_tile_skeleton_ablation.json):
+// at 12288 x 3072 x 4608 rows the full kernel takes 382 us (0.91 PFLOP/s) on a box where unpack + hipBLASLt takes 311-323; without the decode 330, without
+// decode AND LDS-DMA 269, MFMAs alone 213.  A standalone harness (tests/microbench/gemm_skel.hip) ran the no-decode skeleton as a real dense GEMM in
+// every geometry the verdict named -- 16 waves of 64 x 64, 8 of 128 x 64, 4 of 128 x 128 (accumulators in AGPRs), BK 32 / 64, LDS rings 2-4 deep, three
+// tile orders, fragments prefetched across the barrier: 0.86-1.01 PFLOP/s with real loads, 1.21-1.29 with NO loads at all, against the 1.35 the stop
+// rule asked for.  The reason is power, not scheduling: with the operands coming out of LDS the matrix pipes are busy 91-96 % of the cycles -- at a
+// shader clock of 1.70-1.78 GHz; an MFMA-only loop gets 2.2-2.4 GHz with near-zero operands and 1.87-1.91 GHz (1.60-1.67 PFLOP/s on this grid of
+// 3.375 tile rounds) with random ones.  Every joule the decode's VALU work and the LDS traffic add comes out of the clock of the matrix pipe, so a fused
+// kernel cannot beat a memory-bound unpack followed by a GEMM that already sits at that wall.  Hence: opt-in, capped at 256 rows of x by the callers.
 //
 // Numerics: weights = the reference's values bit for bit; products exact in fp32; fp32 accumulation in k order inside the MFMA,
 // K-steps in order, no K split (deterministic).  Like any GEMM against another GEMM the result differs from hipBLASLt's by
@@ -53,7 +62,10 @@ constexpr int GT_TILE = 256 * GT_PITCH;                  // one X or W tile: 16 
                                are already on their way while the first half runs); 0 = nothing; A/B builds */
 #endif
 #ifndef GGQ_GT_ABLATE
-#define GGQ_GT_ABLATE 0     /* timing ablations for EXPERIMENTS.md (wrong results!): 1 = K-steps without the decode, 2 = without the MFMAs */
+#define GGQ_GT_ABLATE 0     /* timing ablations for EXPERIMENTS.md (wrong results!): 1 = K-steps without the decode, 2 = without the MFMAs;
+                               skeleton decomposition (round 4), all without the decode: 3 = MFMAs on loop-invariant registers (no fragment reads; DMA + barriers
+                               stay), 4 = no LDS-DMA of x / packed spans (fragment reads + MFMAs + barriers), 5 = MFMAs only (no reads, no DMA, no barriers):
+                               the ceiling of this grid -- tile quantisation and the clock under matrix load */
 #endif
 #ifndef GGQ_GT_XRING
 #define GGQ_GT_XRING 1      /* a third x buffer where it fits: x tiles requested two K-steps ahead (0 = one step ahead); A/B builds */
@@ -264,10 +276,18 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         for (int kk = 0; kk < 2; kk++) {
             const uint32_t col = (((uint32_t)(2 * kk) + hk) ^ fswz) * 16u;
             u32x4 wa[2], xb[MT];
+#if GGQ_GT_ABLATE == 3 || GGQ_GT_ABLATE == 5   /* operands from registers: the matrix pipe alone */
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) wa[nt] = u32x4{lane + col, lane, (uint32_t)nt, 0x3c003c00u};
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) xb[mt] = u32x4{lane, lane ^ col, (uint32_t)mt, 0x3c003c00u};
+            (void)xs; (void)ws;
+#else
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) wa[nt] = *reinterpret_cast<const u32x4*>(ws + (64u * wn + 32u * (uint32_t)nt + r32) * GT_PITCH + col);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) xb[mt] = *reinterpret_cast<const u32x4*>(xs + ((uint32_t)(32 * MT) * wm + 32u * (uint32_t)mt + r32) * GT_PITCH + col);
+#endif
 #if GGQ_GT_SETPRIO == 3            /* A/B builds: priority 1 only while the MFMAs issue, not for the fragment reads */
             __builtin_amdgcn_s_setprio(1);
 #endif
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
         uint8_t* const wcur = wt + P * GT_TILE;
         uint8_t* const xnxt = xt + (XR == 3 ? (step + 2u) % 3u : (uint32_t)(P ^ 1)) * GT_TILE;    // XR = 3: the buffer of step + 2 (read last at step - 1)
         uint8_t* const wnxt = wt + (P ^ 1) * GT_TILE;
-        if (DECODE && (step + 1) % STEPS == 0) {
+        if (GGQ_GT_ABLATE < 4 && DECODE && (step + 1) % STEPS == 0) {
             // the next K-step opens a new span: every decode of the old one finished before the previous barrier
             const uint32_t span = (step + 1) / STEPS;
             if constexpr (GG::DBUF) {
@@ -331,12 +351,12 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
             }
             prescale(span);                             // the new span's bytes are in LDS (fenced steps ago, or just now)
         }
-        if constexpr (DECODE) {
+        if constexpr (DECODE && GGQ_GT_ABLATE < 4) {
             // x tile of step + 2 (XR = 3: two K-steps to land) or of step + 1; clamped at the end: a harmless re-read into a buffer nobody reads
             if constexpr (XR == 3) xdma(step + 2 < n_steps ? step + 2 : n_steps - 1, xnxt);
             else xdma(step + 1, xnxt);
         }
-#if GGQ_GT_ABLATE == 1             /* timing ablation (wrong results): no decode */
+#if GGQ_GT_ABLATE == 1 || GGQ_GT_ABLATE >= 3   /* timing ablation (wrong results): no decode */
         mma(xcur, wcur);
         if constexpr (false)
 #elif GGQ_GT_ABLATE == 2           /* timing ablation (wrong results): no MFMAs */
@@ -356,8 +376,12 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
 #endif
             mma(xcur, wcur);
         }
+#if GGQ_GT_ABLATE == 5
+        asm volatile("" ::: "memory");
+#else
         if constexpr (XR == 3) ring_fence();
         else dma_fence();
+#endif
     };
     auto main_loop = [&](auto pong_tag) {
         using T0 = std::integral_constant<int, 0>;
@@ -379,6 +403,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here
     // row = output column n inside its 32-block, col = row of x inside its 32-block.
     uint8_t* const ep = smem + wave * 4096;
+    const Window ywin = window((gptr)y_ + ((uint64_t)m0 * n_rows + n0) * 2, 0xFFFFFFFFu);            // this tile of y: offsets < 256 rows x n_rows x 2 B
     const uint32_t nbase = n0 + 64u * wn, mbase = m0 + (uint32_t)(32 * MT) * wm;
     float bias[2][4][4];
 #pragma unroll
@@ -417,7 +442,7 @@ __global__ __launch_bounds__(WM * 256) void linear_tile(const uint8_t* __restric
             const uint32_t row = (lane >> 3) + 8u * (uint32_t)i, p = lane & 7u;
             const u32x4 v = *reinterpret_cast<const u32x4*>(ep + row * 128u + ((p ^ (row & 7u)) * 16u));
             const uint32_t mr = mbase + 32u * (uint32_t)mt + row, nc = nbase + 8u * p;
-            if (mr < m && nc < n_rows) gstore<false>((gptr)y_ + ((uint64_t)mr * n_rows + nc) * 2, v);       // n_rows % 8 == 0 (host)
+            if (mr < m && nc < n_rows) wstore(ywin, ((mr - m0) * n_rows + (nc - n0)) * 2u, v);              // n_rows % 8 == 0, n_rows <= 4 M (host)
         }
         wave_sync();
     }

@@ -2,9 +2,6 @@
 #include "ggq_linear.hpp"
 #include "ggq_mfma.hpp"
 #include "ggq_gemm.hpp"
-#ifdef GGQ_WITH_TILE64       /* A/B builds only: the K-step-64 variant measured 13 % slower (EXPERIMENTS.md A2b) */
-#include "ggq_gemm64.hpp"
-#endif
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
 
@@ -123,39 +120,9 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
     return launch_tile_wm<F, OUT, GGQ_TILE_WM_DEFAULT>(packed, x, bias, y, m, rows, cols, s);
 }
 
-// ... with K-steps of 64 and per-K-step compact staging (ggq_gemm64.hpp): built, correct, 13 % SLOWER than the K-step-32 kernel (EXPERIMENTS.md
-// A2b), so it is compiled only into A/B builds (-DGGQ_WITH_TILE64; GGQ_TILE64=0 in the environment then switches it off again)
-template <class F, int OUT>
-hipError_t launch_tile_any(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
-{
-#ifdef GGQ_WITH_TILE64
-    if constexpr (Step64<F>::OK) {
-        static const bool enabled = lab_int("GGQ_TILE64", 0, 1) != 0;
-        if (enabled) {
-            constexpr uint32_t lds = (uint32_t)Gemm64Geom<F>::LDS_BYTES;
-            static_assert(lds <= 160 * 1024, "one workgroup's LDS");
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            static std::atomic<uint64_t> raised{0};
-            const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
-            if (!(raised.load(std::memory_order_relaxed) & bit)) {
-                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile64<F, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                raised.fetch_or(bit, std::memory_order_relaxed);
-            }
-            const uint32_t tiles_m = (m + GT_BM - 1) / GT_BM, tiles_n = (rows + GT_BN - 1) / GT_BN;
-            hipLaunchKernelGGL((linear_tile64<F, OUT>), dim3(tiles_m * tiles_n), dim3(GT_THREADS), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
-                               static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, tiles_m, tiles_n);
-            return hipGetLastError();
-        }
-    }
-#endif
-    return launch_tile<F, OUT>(packed, x, bias, y, m, rows, cols, s);
-}
-
 constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4 (K-split kernel), then the 256 x 256 shared-tile kernel
 struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][shape]
-#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile_any<F, OUT>}
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>}
 #define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
@@ -189,15 +156,18 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     // shared-tile kernel from there on (profiles/r03_gemm_tile_bench.json).
     int shape;
     if (tile_rows == 0) {
-        // the shared-tile kernel needs enough 256 x 256 tiles to fill the chip (one workgroup per CU, 256 CUs): with fewer than half as many
-        // tiles as CUs the K-split kernel's 32-column workgroups win (emulated FLUX step at 512 / 1024 tokens, profiles/r03_flux_forward_emulation_fused.json)
+        // the fastest FUSED shape for (m, rows).  The shared-tile kernel needs enough 256 x 256 tiles to fill the chip (one workgroup per CU, 256 CUs):
+        // measured crossover against the K-split kernel's 32-column workgroups (profiles/r03_gemm_tile_bench.json): 48 tiles K-split wins by 35-80 %,
+        // 84 tiles (21504 x 3072 at 256 rows) the shared tile by 13 %, 192+ tiles by 2x.  Whether ANY fused shape beats unpack + hipBLASLt is the
+        // caller's question (fused.linear_mfma declines above 256 rows of x unless a tile is forced: profiles/r04_gemm_skeleton_sweep.json).
         const uint32_t n_tiles = ((m + GT_BM - 1) / GT_BM) * ((rows + GT_BN - 1) / GT_BN);
-        const bool tile_ok = m >= tile_min_m() && rows % 8u == 0 && n_tiles >= 128u;
+        const bool tile_ok = m >= tile_min_m() && rows % 8u == 0 && rows <= (1u << 22) && aligned16(y) && n_tiles >= 80u;
         shape = m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2));
     }
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
-    if (shape == 3 && rows % 8u != 0) return GGQ_ERR_ARG;
+    if (shape == 3 && (rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;          // 16-byte pieces of y; 32-bit offsets inside a tile's rows of y
+    if (shape == 3 && !aligned16(y)) return GGQ_ERR_ALIGN;                                // the shared-tile epilogue stores 16-byte vectors
     const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
     return err == hipSuccess ? GGQ_OK : hip_fail(err);
 }

@@ -114,14 +114,26 @@ def linear_small(x, weight, bias=None, dequant_dtype=None, weight_to=None):
     return _run(_small_call, "ggq_linear_small", qid, weight, rows, cols, xf, m, bias, x, (), weight_to)
 
 
-def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None):
-    """``F.linear(x, dequantize_tensor(weight, x.dtype), bias)`` for any number of rows of x, on the matrix cores, from the packed
-    blocks (include/ggq.h ``ggq_linear_mfma``).  x: (..., cols) fp16 / bf16 on the GPU; weight: GGMLTensor of logical shape
-    (rows, cols) with cols % 256 == 0.  Weights bit-identical to the reference's; fp32 accumulation in the kernel's own order
-    (tolerance parity, tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take."""
+AUTO_MAX_ROWS = 256      # rows of x up to which a fused MFMA shape beats dequantize + F.linear on FLUX / SD3.5 / T5 layer shapes (profiles/r03_gemm_tile_bench.json;
+                         # above it the shared-tile kernel runs at 0.9-1.0 PFLOP/s against hipBLASLt's 1.2-1.3 on the freshly written, cache-hot dense weight,
+                         # and profiles/r04_gemm_skeleton_sweep.json shows why that gap does not close: DESIGN.md section 4c)
+
+
+def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None, auto_max_rows=AUTO_MAX_ROWS):
+    """``F.linear(x, dequantize_tensor(weight, x.dtype), bias)`` on the matrix cores, from the packed blocks (include/ggq.h
+    ``ggq_linear_mfma``).  x: (..., cols) fp16 / bf16 on the GPU; weight: GGMLTensor of logical shape (rows, cols) with
+    cols % 256 == 0.  Weights bit-identical to the reference's; fp32 accumulation in the kernel's own order (tolerance parity,
+    tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take.
+
+    ``tile_rows=0`` (auto) never picks something slower than the default path: the library chooses the fastest fused shape for
+    (rows of x, rows of the weight), and inputs of more than ``auto_max_rows`` rows are DECLINED (GGQUnsupported: the caller keeps
+    dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
+    kernel) or ``auto_max_rows=None`` forces the fused kernel at any size."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
     if tile_rows not in (0, 32, 64, 128, 256) or (tile_rows == 256 and rows % 8):
         raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 32, 64, 128 or 256 (the shared-tile kernel, rows % 8 == 0)")
+    if tile_rows == 0 and auto_max_rows is not None and m > auto_max_rows:
+        raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x -- above {auto_max_rows} rows dequantize + F.linear is the faster path; pass tile_rows= to force a fused shape")
     if _mfma_call is None:
         _bind()
     return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)

@@ -250,7 +250,7 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
                 if small_m and m <= MAX_ROWS:
                     return linear_small(input, weight, self.bias, self.dequant_dtype, weight_to=input.device)
                 if m <= mfma_max_m:
-                    return linear_mfma(input, weight, self.bias, self.dequant_dtype, weight_to=input.device)
+                    return linear_mfma(input, weight, self.bias, self.dequant_dtype, weight_to=input.device, auto_max_rows=mfma_max_m)
             except unsupported:
                 pass
         return reference_forward(self, input)

@@ -30,17 +30,47 @@ def test_mfma_linear_against_fp64_reference(pkg, name, kind):
                                            (333, 512, 129, True, 128), (40, 2304, 260, True, 256), (32, 1280, 96, False, 0),
                                            # the shared-tile kernel (256 x 256 output tiles, ggq_gemm.hpp): several tiles both ways with ragged
                                            # edges; exactly one tile and one span; 9 spans (the staging buffer is refilled 8 times) x 3 tiles of x;
-                                           # fewer output columns than one MFMA block; picked automatically from m
+                                           # fewer output columns than one MFMA block; shape picked by the library (2 tiles: the K-split kernel)
                                            (520, 1024, 300, True, 256), (256, 256, 256, False, 256), (264, 2304, 513, True, 256), (8, 512, 1000, False, 256),
                                            (304, 768, 200, True, 0)):
         blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
         w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
         x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
         bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if with_bias else None
-        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile)
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None)
         assert y.shape == (m, rows) and y.dtype == dtype
         _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
-        assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=tile))          # deterministic: fixed reduction order
+        assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None))          # deterministic: fixed reduction order
+
+
+@pytest.mark.parametrize("name", ["Q4_K", "Q8_0", "Q6_K"])
+def test_auto_dispatch_reaches_the_shared_tile_kernel(pkg, name):
+    """tile_rows=0 with enough 256 x 256 tiles (>= 80: here 9 x 9 = 81) must run the shared-tile kernel -- its bits, not the K-split kernel's
+    (no test reached that kernel through the library's own choice); with 4 x 9 = 36 tiles the K-split kernel; and the host-side
+    auto policy declines more than 256 rows of x unless told otherwise (dequantize + F.linear is faster there)."""
+    q = pkg.qtypes.Q[name]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(31)
+    rows, cols, m = 2304, 256, 2304
+    blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=77, mode="signed")
+    w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+    x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    with pytest.raises(pkg.dequant.GGQUnsupported):
+        pkg.fused.linear_mfma(x, w)                                                         # 2304 rows of x: declined by default
+    auto = pkg.fused.linear_mfma(x, w, auto_max_rows=None)
+    tile, ksplit = pkg.fused.linear_mfma(x, w, tile_rows=256), pkg.fused.linear_mfma(x, w, tile_rows=128)
+    _check(auto, x, _dense_weight(q, blocks, "bf16", rows, cols), None, DT["bf16"][1], cols)
+    assert torch.equal(auto, tile)
+    assert not torch.equal(ksplit, tile)                                                    # (the K-split kernel sums in another order: the two are distinguishable)
+    small = pkg.fused.linear_mfma(x[:1024], w, auto_max_rows=None)                          # 4 x 9 tiles: the library stays with the K-split kernel
+    assert torch.equal(small, pkg.fused.linear_mfma(x[:1024], w, tile_rows=128)) and not torch.equal(small, tile[:1024])
+    assert torch.equal(pkg.fused.linear_mfma(x[:200], w), pkg.fused.linear_mfma(x[:200], w, tile_rows=64))   # <= 256 rows: served by default
+    # an output view that is not 16-byte aligned cannot take the shared-tile epilogue's vector stores: the C entry point says so
+    import ctypes
+    L = pkg._native.lib()
+    y = torch.empty(m * rows + 8, dtype=torch.bfloat16, device=DEV)
+    rc = L.ggq_linear_mfma(int(q), w.data_ptr(), rows, cols, x.data_ptr(), m, None, y.data_ptr() + 2, pkg._native.BF16, 256, torch.cuda.current_stream().cuda_stream)
+    assert rc == pkg._native.GGQ_ERR_ALIGN
 
 
 def _exact_blocks(pkg, q, rows, cols, seed):
@@ -129,7 +159,7 @@ def test_mfma_randomized_sweep(pkg):
         w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
         x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
         bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if rng.integers(2) else None
-        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile)
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None)
         try:
             _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
         except AssertionError as e:

@@ -69,7 +69,7 @@ def main():
             for t in (int(v) for v in args.tiles.split(",")):
                 if t and t > 32 and t >= 2 * m and t != 32:
                     continue                                     # a tile more than twice m only wastes MFMAs
-                us = round(timed(lambda w: pkg.fused.linear_mfma(x, w, tile_rows=t), pool, reps), 1)
+                us = round(timed(lambda w: pkg.fused.linear_mfma(x, w, tile_rows=t, auto_max_rows=None), pool, reps), 1)
                 row[f"fused tile={t or 'auto'}"] = us
                 best = us if best is None else min(best, us)
             row["fused_best_vs_default"] = round(row["dequant+F.linear"] / best, 2)
