@@ -100,6 +100,9 @@ struct Engine {
         for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + TEAM * u) * 16) = pf[u];
         team_sync();
         const uint64_t b0 = w.lg * (uint64_t)G;
+        // (NTS = false: the product's write-through Window stores, ggq_device.hpp)
+        constexpr uint32_t OB = (uint32_t)OutBytes<OUT>::V;
+        [[maybe_unused]] const Window win = window(w.out + b0 * (uint64_t)(BS * OB), (uint32_t)(G * BS) * OB);
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
             const int unit = lane + TEAM * s;
@@ -108,7 +111,8 @@ struct Engine {
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
                 const Fields f = F::template fields<true>(slice + a + bl * TS, j);
-                emit<F, ARITH, OUT, NTS>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
+                if constexpr (NTS) emit<F, ARITH, OUT, true>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
+                else emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { wstore(win, (uint32_t)(bl * BS + j * 8 + piece * Layout<OUT>::ELEMS) * OB, v); });
             }
             if (s + 1 < NCH) store_throttle<THR>();
         }
@@ -220,6 +224,51 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
         return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};
     });
 }
+
+// ---- round 4: lane-to-lane exchange (DPP) instead of LDS reads for bytes two lanes need (Next #8; north_star: "sub-byte
+// nibble extraction via DPP/permlane").  Same values as the shipped formats (parity-checked by the harness); only where the bytes come from differs.
+// The engine deals chunks to lanes in order (chunk = lane + 64 s), which is what makes fixed DPP patterns line up.
+
+// Q4_K: chunks j and j + 4 unpack the LOW and the HIGH nibbles of the same 8 bytes (dequant.py:189-192).  Shipped: both lanes read them from LDS (a
+// broadcast read).  Here: only the lanes of the even sub-blocks read; the lane four up gets the two dwords by `row_shr:4` and shifts its nibbles down.
+struct FmtQ4_K_DPP : FmtQ4_K {
+    template <bool LDS>
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
+    {
+        const int sb = j >> 2;
+        const u32x4 hdr = *reinterpret_cast<const u32x4*>(b);
+        Fields f;
+        k_scale_min(hdr, sb, f.sc, f.mn);
+        u32x2 w{0u, 0u};
+        if ((sb & 1) == 0) w = lds_ld8<8, LDS>(b + 16 + 32 * (sb >> 1) + 8 * (j & 3));
+        const uint32_t sx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+        const uint32_t sy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w.y, 0x114, 0xF, 0xF, false);
+        const bool odd = (sb & 1) != 0;
+        f.t0 = ((odd ? sx : w.x) >> (odd ? 4 : 0)) & 0x0F0F0F0Fu;
+        f.t1 = ((odd ? sy : w.y) >> (odd ? 4 : 0)) & 0x0F0F0F0Fu;
+        f.dm = hdr.x;
+        return f;
+    }
+};
+
+// Q8_0: a chunk's 8 bytes start 2 bytes into a 34-byte block, i.e. at a 2-byte-aligned address in every other block: the shipped decode reads the
+// three enclosing aligned dwords and funnel-shifts.  The third dword is the first dword of the NEXT chunk's read whenever that chunk is in the same
+// block: here it comes from the lane one up (`row_shl:1`), and only the last chunk of a block (whose neighbour starts a block of the other
+// alignment) reads its own third dword.
+struct FmtQ8_0_DPP : FmtQ8_0 {
+    template <bool LDS>
+    GGQ_DEV static Fields fields(const uint8_t* b, int j)
+    {
+        const uint8_t* p = b + 2 + 8 * j;
+        const uint32_t sh = (uint32_t)reinterpret_cast<uintptr_t>(p) & 2u;
+        const uint8_t* q = p - sh;
+        const uint32_t d0 = lds_dword(q), d1 = lds_dword(q + 4);
+        uint32_t d2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d0, 0x101 /* row_shl:1: from the lane one up */, 0xF, 0xF, false);
+        if (j == 3 && sh) d2 = lds_dword(q + 8);                   // (lane 15 of a DPP row always holds a j == 3 chunk: no row-edge case left)
+        const uint32_t x = __builtin_amdgcn_alignbyte(d1, d0, sh), y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        return Fields{x ^ 0x80808080u, y ^ 0x80808080u, lds_u16(b), 0, 0};
+    }
+};
 
 }  // namespace lab
 }  // namespace ggq

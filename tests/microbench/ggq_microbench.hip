@@ -537,6 +537,43 @@ static void skeletons()
     HIP_CHECK(hipFree(in)); HIP_CHECK(hipFree(out));
 }
 
+// Round 4 (Next #5, "record the ceiling experiment"): what a LAYER-SIZED launch can reach at all -- the Q4_K traffic skeleton (72 load
+// units in, 4 KiB out per wave, no LDS, no arithmetic) launched once per "tensor" over a rotating pool far beyond the Infinity Cache, exactly like
+// the per-layer dequant launches, for the FLUX layer sizes.  The gap between this and the whole-pool rate is ramp + drain of a 5-20 us kernel.
+template <int NST, int WAVES>
+static void layer_ceiling_one(Timer& T, ggq::u32x4* in, ggq::u32x4* out, uint64_t pool_out_bytes, uint64_t elements)
+{
+    const uint64_t out_bytes = elements * 2, n_waves = out_bytes / (NST * 1024ull), blocks = (n_waves + WAVES - 1) / WAVES;
+    const uint64_t in_units = n_waves * 18ull * NST;                       // 72 units per 4 KiB of output = Q4_K's 0.5625 B per element
+    const int n_t = (int)(pool_out_bytes / out_bytes);
+    double med, mn;
+    T.run([&] {
+        for (int t = 0; t < n_t; t++)
+            hipLaunchKernelGGL((k_skel<NST, 18 * NST, 1, true, WAVES, -1>), dim3((uint32_t)blocks), dim3(WAVES * 64), 0, nullptr, in + (uint64_t)t * in_units,
+                               out + (uint64_t)t * (out_bytes / 16), n_waves);
+    }, 3, 15, med, mn);
+    const double bytes = (double)n_t * ((double)out_bytes + (double)in_units * 16.0);
+    printf("LAYER-CEILING %5.1f M elements  %d launches per pass  %d waves x %d KiB rows per workgroup  %7.3f us per launch  %8.1f GB/s median (%.1f%% of 8 TB/s)  best %8.1f\n", elements / 1e6, n_t, WAVES,
+           NST, med * 1e3 / n_t, bytes / med / 1e6, bytes / med / 1e6 / 80.0, bytes / mn / 1e6);
+    fflush(stdout);
+}
+
+static void layer_ceiling()
+{
+    Timer T;
+    const uint64_t pool = 1200ull << 20;
+    ggq::u32x4 *in, *out;
+    HIP_CHECK(hipMalloc(&in, pool)); HIP_CHECK(hipMalloc(&out, pool));
+    k_fill_rand<<<4096, 256>>>(reinterpret_cast<uint64_t*>(in), pool / 8, 1);
+    HIP_CHECK(hipDeviceSynchronize());
+    for (uint64_t el : {3072ull * 3072, 9216ull * 3072, 12288ull * 3072, 21504ull * 3072, 600ull << 20 >> 1}) {
+        layer_ceiling_one<4, 4>(T, in, out, pool, el);                     // one-wave teams x 4 KiB
+        layer_ceiling_one<8, 4>(T, in, out, pool, el);
+        layer_ceiling_one<2, 4>(T, in, out, pool, el);
+    }
+    HIP_CHECK(hipFree(in)); HIP_CHECK(hipFree(out));
+}
+
 // ---- counter study: a fixed sequence of kernel variants for rocprofv3 --pmc passes
 template <class F, int G, bool NTL, bool NTS, int WAVES, int XCD, bool DIRECT, int THR>
 static void launch3(Pool& P)
@@ -663,6 +700,30 @@ static void ab_layer_bf16(const char* name, int qi, std::initializer_list<uint64
         ab_add_layer<F, GB, 4, false, true, B, false>(ab, name, Q, 0);         // one-wave teams x 2048, 4 per workgroup
         ab_add_layer<F, GB, 1, false, true, B, false>(ab, name, Q, 0);         // one-wave teams x 2048
         ab_add_layer<F, 4 * GB, 4, true, true, B, true>(ab, name, Q, 0);       // TuneMid with non-temporal stores (reference point)
+        ab.run(12, 4);
+        free_pool(Q);
+    }
+}
+
+// Round 4 (Next #5): group sizes that make the number of workgroups a whole multiple of the 256 CUs for the FLUX layer sizes --
+// 3072 x 3072 Q4_K = 36864 super-blocks: 24 per team = 1536 workgroups = 6 per CU exactly, where the shipped 32 (TuneMid) gives 1152 = 4.5 per CU.
+template <class F, int GB>
+static void ab_layer_balance(const char* name, int qi, std::initializer_list<uint64_t> sizes)
+{
+    constexpr int B = ggq::OUT_BF16;
+    for (uint64_t el : sizes) {
+        const int n_t = (int)std::max<uint64_t>(6, std::min<uint64_t>(48, (600ull << 20) / (el * 2)));
+        Pool Q = make_pool(QTS[qi], n_t, el);
+        printf("LAYER-BALANCE %s: %d tensors of %llu elements (%.1f M), one launch each, bf16 result, sc1 stores; workgroups per CU at 4096 / 6144 / 8192 / 12288 / 16384 elements: %.2f %.2f %.2f %.2f %.2f\n",
+               name, n_t, (unsigned long long)el, el / 1e6, el / 4096.0 / 256, el / 6144.0 / 256, el / 8192.0 / 256, el / 12288.0 / 256, el / 16384.0 / 256);
+        AB ab;
+        ab_add_layer<F, 2 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 4096
+        ab_add_layer<F, 3 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 6144
+        ab_add_layer<F, 4 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 8192 (TuneMid)
+        ab_add_layer<F, 6 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 12288
+        ab_add_layer<F, 8 * GB, 4, true, true, B, false>(ab, name, Q, 0);      // 4 waves x 16384
+        ab_add_layer<F, 3 * GB, 2, true, true, B, false>(ab, name, Q, 0);      // 2 waves x 6144
+        ab_add_layer<F, 6 * GB, 8, true, true, B, false>(ab, name, Q, 0);      // 8 waves x 12288
         ab.run(12, 4);
         free_pool(Q);
     }
@@ -870,6 +931,30 @@ static void ab_q3k_line_exact()
     ab_add<F, 32, false, true, 4, 0, false, -1, 1, true>(ab, "Q3_K", P, 0, 4);           // round 1's best workgroup-team shape, for reference
     ab.run(12, 4);
     free_pool(P);
+}
+
+// Round 4 (Next #8): bytes two lanes need -- by DPP from the neighbour lane instead of a second LDS read -- against the shipped
+// decode, at the shipped launch shapes (workgroup teams x 4096 elements with XCD runs; one-wave teams beside them), 3.0 G-element pool.
+static void ab_dpp()
+{
+    { Pool P = make_pool(QTS[7], 64);
+      printf("POOL Q4_K pairs=64 packed %.2f GB out %.2f GB\n", P.packed_bytes / 1e9, P.out_bytes / 1e9);
+      AB ab;
+      ab_add<ggq::FmtQ4_K, 16, true, true, 4, 0, false, -1, 1, true>(ab, "Q4_K shipped (LDS broadcast reads + v_perm)", P, 0, 5);
+      ab_add<ggq::lab::FmtQ4_K_DPP, 16, true, true, 4, 0, false, -1, 1, true>(ab, "Q4_K DPP row_shr:4 for the high-nibble lanes", P, 0, 5);
+      ab_add<ggq::FmtQ4_K, 8, true, true, 1, 0, false, -1, 1, false>(ab, "Q4_K shipped, one-wave teams", P, 0, 6);
+      ab_add<ggq::lab::FmtQ4_K_DPP, 8, true, true, 1, 0, false, -1, 1, false>(ab, "Q4_K DPP, one-wave teams", P, 0, 6);
+      ab.run(12, 4);
+      free_pool(P); }
+    { Pool P = make_pool(QTS[4], 64);
+      printf("POOL Q8_0 pairs=64 packed %.2f GB out %.2f GB\n", P.packed_bytes / 1e9, P.out_bytes / 1e9);
+      AB ab;
+      ab_add<ggq::FmtQ8_0, 128, true, true, 4, 0, false, -1, 1, true>(ab, "Q8_0 shipped (3 aligned dwords + v_alignbyte)", P, 0, 5);
+      ab_add<ggq::lab::FmtQ8_0_DPP, 128, true, true, 4, 0, false, -1, 1, true>(ab, "Q8_0 DPP row_shl:1 for the third dword", P, 0, 5);
+      ab_add<ggq::FmtQ8_0, 64, true, true, 1, 0, false, -1, 1, false>(ab, "Q8_0 shipped, one-wave teams", P, 0, 6);
+      ab_add<ggq::lab::FmtQ8_0_DPP, 64, true, true, 1, 0, false, -1, 1, false>(ab, "Q8_0 DPP, one-wave teams", P, 0, 6);
+      ab.run(12, 4);
+      free_pool(P); }
 }
 
 static void ab_small_all()      // profiles/r01_microbench_p_q2k_q3k_shapes.txt
@@ -1263,6 +1348,12 @@ int main(int argc, char** argv)
         ab_layer_bf16<ggq::FmtQ5_0, 64>("Q5_0", 2, {2432ull * 2432, 7296ull * 2432, 9728ull * 2432, 14592ull * 2432});
     }
     if (what == "abq3k") ab_q3k_line_exact();
+    if (what == "abdpp") ab_dpp();
+    if (what == "ceillayer") layer_ceiling();
+    if (what == "ablayer4") {     // round 4: workgroup counts that divide evenly over the CUs
+        ab_layer_balance<ggq::FmtQ4_K, 8>("Q4_K", 7, {3072ull * 3072, 9216ull * 3072, 12288ull * 3072, 3072ull * 15360, 18432ull * 3072, 21504ull * 3072});
+        ab_layer_balance<ggq::FmtQ5_K, 8>("Q5_K", 8, {9216ull * 3072});
+    }
     if (what == "ablds") {          // round 3: LDS-staged vs no-LDS ("direct", zero bank conflicts by construction) for the 2-byte-aligned legacy formats
         ab_big<ggq::FmtQ4_0, 64>("Q4_0", 0, 64);
         ab_big<ggq::FmtQ8_0, 64>("Q8_0", 4, 64);
