@@ -88,12 +88,14 @@ class World:
     decision about the other one) and the RCCL group the timed regions are fenced through (backend "nccl" IS RCCL on ROCm).  If the
     RCCL group cannot be created or its first all-reduce fails on ANY rank, every rank learns so over the control group and the
     fences fall back to gloo -- the line then says so in ``world.backend`` instead of the run dying (Next #1e).
-    GGQ_BENCH_BACKEND=gloo is the TEST RIG: no RCCL attempt, and ranks may share a device (N ranks on the one GPU of a test box)."""
+    GGQ_BENCH_BACKEND=gloo is the TEST RIG: no RCCL attempt, and ranks may share a device (N ranks on the one GPU of a test box);
+    GGQ_BENCH_BACKEND=try-nccl is the rig WITH the RCCL attempt -- on a one-GPU box RCCL refuses two ranks on one device, which is how the
+    fallback itself gets exercised (tests/test_gpu_multirank.py)."""
 
     def __init__(self, rank, local_rank, size, device, launched):
         self.rank, self.local_rank, self.size, self.device = rank, local_rank, size, device
         self.active = launched
-        self.rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") == "gloo"
+        self.rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") in ("gloo", "try-nccl")
         self.fence_group, self.backend = None, None
         if not launched:
             return
@@ -101,12 +103,12 @@ class World:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=size)
-        if self.rig:
+        if os.environ.get("GGQ_BENCH_BACKEND") == "gloo":
             self.backend = "gloo (GGQ_BENCH_BACKEND=gloo test rig: no RCCL attempt, ranks may share a device)"
             return
         err, pg = None, None
         try:
-            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=600), device_id=device)
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("GGQ_BENCH_RCCL_TIMEOUT_S", "600"))), device_id=device)
             t = torch.ones(1, device=device)
             dist.all_reduce(t, group=pg)
             torch.cuda.synchronize(device)
@@ -117,7 +119,7 @@ class World:
         errs = self.gather(err)
         bad = [e for e in errs if e]
         if bad:
-            self.backend = f"gloo (RCCL group failed on {len(bad)} of {size} ranks, fences fell back to gloo: {bad[0]})"
+            self.backend = f"gloo (RCCL group failed on {len(bad)} of {size} ranks, fences fell back to gloo: {bad[0]})" + (" [test rig: ranks share a device]" if self.rig else "")
         else:
             self.fence_group, self.backend = pg, "nccl"
 
@@ -874,7 +876,7 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # GGQ_BENCH_BACKEND=gloo (test rig): exercise the N > 1 code path on a box with fewer GPUs than ranks -- ranks share
     # devices round-robin and fence through gloo.  The driver's runs use the default: RCCL fences, one rank per GPU.
-    rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") == "gloo"
+    rig = os.environ.get("GGQ_BENCH_BACKEND", "nccl") in ("gloo", "try-nccl")
     n_dev = torch.cuda.device_count()
     if not rig and local_rank >= n_dev:
         sys.exit(f"LOCAL_RANK={local_rank} but only {n_dev} GPU(s) visible: one rank per GPU")

@@ -29,8 +29,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(nproc, script_args, timeout=600):
-    env = dict(os.environ, GGQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(nproc, script_args, timeout=600, backend="gloo"):
+    env = dict(os.environ, GGQ_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", GGQ_BENCH_RCCL_TIMEOUT_S="120")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -131,6 +131,19 @@ def test_bench_sd35_t5_eight_ranks_on_one_gpu():
     line = _bench(8, ["--workload", "sd35-t5"], cpu_seconds=4)
     assert all(k in line for k in CONTRACT) and line["n_gpus"] == 8 and line["scaling"] == "strong"
     _self_proving(line, 8, total=549)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_failure_falls_back_to_gloo_fences_and_says_so():
+    """GGQ_BENCH_BACKEND=try-nccl: the rig WITH the RCCL attempt.  Two ranks on this box's one GPU: RCCL refuses (duplicate device), every rank learns
+    so over the gloo control group, the fences fall back to gloo and the line says why in world.backend -- the run does not die (Next #1e)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs: RCCL would simply work")
+    args = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--regions", "3", "--no-per-qtype", "--no-per-mode", "--cpu-seconds", "2", "--no-workloads", "--pairs", "4"]
+    proc = _run(2, args, timeout=800, backend="try-nccl")
+    (line,) = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert line["world"]["backend"].startswith("gloo (RCCL group failed on"), line["world"]["backend"]
+    assert line["n_gpus"] == 2 and line["cpu_baseline"]["parity_vs_gpu"].startswith("bit-exact (2 x 8 = 16 tensors on 2 ranks")
 
 
 @pytest.mark.timeout(600)
