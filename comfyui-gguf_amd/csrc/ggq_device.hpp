@@ -519,11 +519,11 @@ GGQ_DEV Window window(gptr base, uint32_t bytes)
 {
     return Window{__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)base, (short)0, (int)bytes, 0x00020000)};
 }
-template <class T>
+template <int AUX = STORE_AUX, class T>
 GGQ_DEV void wstore(const Window& w, uint32_t byte_off, T v)
 {
     static_assert(sizeof(T) == 16, "16-byte stores");
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w.rsrc, (int)byte_off, 0, STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), w.rsrc, (int)byte_off, 0, AUX);
 }
 
 template <bool NT>

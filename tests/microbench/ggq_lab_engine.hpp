@@ -32,8 +32,9 @@ GGQ_DEV void store_throttle()
 // group start is then taken from the ADDRESS, not from the offset inside the tensor.
 // LPOL >= 0 (harness only): the group's bytes are fetched with BUFFER loads carrying that cache policy (aux bits: 1 = sc0, 2 = nt,
 // 16 = sc1) from a wave-uniform resource whose range ends at the tensor's last byte, instead of global loads with NTL.
+// SPOL >= 0 (harness only): every store is a Window (buffer) store carrying that cache policy (same aux bits), whatever NTS says.
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          bool SKEW = false, int LPOL = -1>
+          bool SKEW = false, int LPOL = -1, int SPOL = -1>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -111,7 +112,8 @@ struct Engine {
             const uint64_t gb = b0 + (uint64_t)bl;
             if (FULL || gb < w.n_blocks) {
                 const Fields f = F::template fields<true>(slice + a + bl * TS, j);
-                if constexpr (NTS) emit<F, ARITH, OUT, true>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
+                if constexpr (SPOL >= 0) emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { wstore<SPOL>(win, (uint32_t)(bl * BS + j * 8 + piece * Layout<OUT>::ELEMS) * OB, v); });
+                else if constexpr (NTS) emit<F, ARITH, OUT, true>(f, piece, w.out, gb * (uint64_t)BS + (uint64_t)(j * 8 + piece * Layout<OUT>::ELEMS));
                 else emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { wstore(win, (uint32_t)(bl * BS + j * 8 + piece * Layout<OUT>::ELEMS) * OB, v); });
             }
             if (s + 1 < NCH) store_throttle<THR>();
@@ -204,11 +206,11 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total
 // which leaves a 1-2 step forward scan instead of a log2(n)-step binary search -- a team holds its wave slots idle during
 // that chain, which costs the multi-wave (COOP) teams most (tests/microbench `ablocate`).
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          int LPOL = -1>
+          int LPOL = -1, int SPOL = -1>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2,
                                                            const uint32_t* __restrict__ coarse, uint32_t coarse_shift)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL>::run(total_groups, xrun_log2, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL, SPOL>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0;                                // last entry with first_group <= g
         if (coarse != nullptr) {
             lo = coarse[g >> coarse_shift];

@@ -1307,6 +1307,44 @@ static void ab_load_policy(const char* name, int qi, uint32_t xr)
     free_pool(P);
 }
 
+// ---- store cache policy on WHOLE-POOL launches (round 4): buffer stores with every aux combination against the shipped non-temporal global stores.
+// (Round 3 swept the policies for layer-sized launches only; the buffer-store builtin makes the sweep one template argument.)
+template <class F, int G, int WAVES, bool COOP, bool NTL, int SPOL>
+static void ab_add_spol(AB& ab, const char* name, Pool& P, uint32_t xrun)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    ab.to_free.push_back(dt);
+    const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s %s G=%d buffer STORES aux=%d:%s%s%s%s xrun=%u", name, COOP ? "coop" : "solo", G, SPOL, (SPOL & 1) ? " sc0" : "", (SPOL & 16) ? " sc1" : "", (SPOL & 2) ? " nt" : "",
+             SPOL ? "" : " plain", xrun);
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, -1, SPOL>), dim3(blocks), dim3(WAVES * 64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, true});
+}
+
+template <class F, int G, bool NTL>
+static void ab_store_policy(const char* name, int qi, uint32_t xr)
+{
+    Pool P = make_pool(QTS[qi], 64);
+    printf("POOL %s pairs=64\n", name);
+    AB ab;
+    ab_add<F, G, NTL, true, 4, 0, false, -1, 1, true>(ab, name, P, 0, xr);                  // shipped: non-temporal GLOBAL stores
+    ab_add_spol<F, G, 4, true, NTL, 2>(ab, name, P, xr);                                    // the same policy through the buffer path (one address VGPR)
+    ab_add_spol<F, G, 4, true, NTL, 0>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 1>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 16>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 17>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 18>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 3>(ab, name, P, xr);
+    ab_add_spol<F, G, 4, true, NTL, 19>(ab, name, P, xr);
+    ab.run(9, 3);
+    free_pool(P);
+}
+
 static void ab_load_policy_all()
 {
     ab_load_policy<ggq::FmtQ4_K, 16, true, true>("Q4_K", 7, 5);
@@ -1349,6 +1387,7 @@ int main(int argc, char** argv)
     }
     if (what == "abq3k") ab_q3k_line_exact();
     if (what == "abdpp") ab_dpp();
+    if (what == "abstore") { ab_store_policy<ggq::FmtQ4_K, 16, true>("Q4_K", 7, 5); ab_store_policy<ggq::FmtQ8_0, 128, true>("Q8_0", 4, 5); }
     if (what == "ceillayer") layer_ceiling();
     if (what == "ablayer4") {     // round 4: workgroup counts that divide evenly over the CUs
         ab_layer_balance<ggq::FmtQ4_K, 8>("Q4_K", 7, {3072ull * 3072, 9216ull * 3072, 12288ull * 3072, 3072ull * 15360, 18432ull * 3072, 21504ull * 3072});
