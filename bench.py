@@ -645,7 +645,9 @@ def observed_world(W):
             "uuid": str(getattr(props, "uuid", "")) or None, "pci_bus_id": getattr(props, "pci_bus_id", None),
             "total_memory_GB": round(props.total_memory / 1e9, 1), "pid": os.getpid()}
     rows = W.gather(mine)
-    ids = {(r["uuid"] or r["pci_bus_id"] or r["device"]) for r in rows}
+    # a physical device = its (uuid, PCI bus id) pair: two ranks share a device only if BOTH coincide (a driver that reports one of them as a
+    # constant must not make a legitimate N-GPU run look like one device); without either, the per-process device index is all there is
+    ids = {(r["uuid"], r["pci_bus_id"]) if (r["uuid"] or r["pci_bus_id"] is not None) else (r["device"],) for r in rows}
     return {"size": W.size, "backend": W.backend, "ranks": rows, "distinct_devices": len(ids)}
 
 
