@@ -44,7 +44,21 @@ hipError_t launch(const void* packed, const void* x, const void* bias, void* y, 
     const uint32_t cus = compute_units(dev);
     const uint32_t need = (rows + LIN_WAVES - 1) / LIN_WAVES;
     uint32_t per_cu = (152u * 1024u) / lds;             // workgroups whose LDS fits one CU (160 KiB, some left to the allocator's granularity) ...
-    per_cu = per_cu > 8u ? 8u : (per_cu < 1u ? 1u : per_cu);   // ... up to the 32 wave slots of a CU at <= 64 VGPRs
+    // ... up to the wave slots this instantiation's register count leaves: 512 VGPRs per SIMD lane, allocated in eights; a workgroup puts one
+    // wave on each SIMD, so workgroups per CU = waves per SIMD (asked once per instantiation)
+    static std::atomic<uint32_t> by_regs{0};
+    uint32_t wps = by_regs.load(std::memory_order_relaxed);
+    if (wps == 0) {
+        hipFuncAttributes fa;
+        wps = 8;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&linear_small<F, OUT, M>)) == hipSuccess && fa.numRegs > 0) {
+            const uint32_t regs = ((uint32_t)fa.numRegs + 7u) & ~7u;
+            wps = 512u / regs;
+            wps = wps > 8u ? 8u : (wps < 1u ? 1u : wps);
+        }
+        by_regs.store(wps, std::memory_order_relaxed);
+    }
+    per_cu = per_cu > wps ? wps : (per_cu < 1u ? 1u : per_cu);
     static const int lab_per_cu = lab_int("GGQ_LIN_PER_CU", 1, 8);   // lab builds only, read once (-1 in the shipped library)
     if (lab_per_cu >= 1 && (uint32_t)lab_per_cu < per_cu) per_cu = (uint32_t)lab_per_cu;
     const uint32_t grid = need < cus * per_cu ? need : cus * per_cu;

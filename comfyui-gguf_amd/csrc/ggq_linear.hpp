@@ -72,6 +72,9 @@ GGQ_DEV void weights8(const Fields& f, uint32_t (&w)[4])
     }
 }
 
+#ifndef GGQ_LIN_UNROLL2
+#define GGQ_LIN_UNROLL2 0      /* A/B builds */
+#endif
 constexpr int LIN_NU_MAX = 6;                    // 16-byte load units per lane per row: rows of up to 6128 packed bytes
 constexpr int LIN_SLICE = LIN_NU_MAX * 64 * 16;  // the LARGEST LDS slice a wave can need for one row (+ up to 15 bytes of leading misalignment)
 constexpr int LIN_WAVES = 4;
@@ -80,8 +83,13 @@ constexpr int LIN_WAVES = 4;
 // unit).  Sized to the row, not to LIN_SLICE: a 3072-column Q4_K row takes 2 KiB, so eight workgroups fit a CU instead of four.
 constexpr uint32_t lin_slice_bytes(uint32_t row_bytes) { return (row_bytes + 15u + 1023u) & ~1023u; }
 
+#if GGQ_LIN_UNROLL2
+#define GGQ_LIN_OCC __attribute__((amdgpu_waves_per_eu(4, 6)))     /* let the scheduler spend registers on hoisted LDS reads: 6 waves per SIMD instead of 8 */
+#else
+#define GGQ_LIN_OCC
+#endif
 template <class F, int OUT, int M>
-__global__ __launch_bounds__(LIN_WAVES * 64) void linear_small(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+__global__ __launch_bounds__(LIN_WAVES * 64) GGQ_LIN_OCC void linear_small(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                                const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
                                                                uint32_t rows, uint32_t cols, uint32_t slice_bytes)
 {
@@ -125,7 +133,27 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_small(const uint8_t* __
         float acc[M];
 #pragma unroll
         for (int mm = 0; mm < M; mm++) acc[mm] = 0.0f;
-        for (uint32_t j = lane; j < chunks; j += 64) {
+        uint32_t j = lane;
+#if GGQ_LIN_UNROLL2
+        // two chunks per trip, every LDS read of both issued before the arithmetic of either: a trip's three dependent LDS round trips (block header,
+        // quants, x) otherwise sit back to back behind s_waitcnt lgkmcnt(0) -- the loop is latency-, not VALU-bound (62 VALU = 124 issue cycles per chunk)
+        for (; j + 64 < chunks; j += 128) {
+            const Fields f0 = F::template fields<true>(slice + a + (j / CPB) * F::TS, (int)(j % CPB));
+            const Fields f1 = F::template fields<true>(slice + a + ((j + 64) / CPB) * F::TS, (int)((j + 64) % CPB));
+            uint32_t w0[4], w1[4];
+            weights8<F, OUT>(f0, w0);
+            weights8<F, OUT>(f1, w1);
+#pragma unroll
+            for (int mm = 0; mm < M; mm++) {
+                acc[mm] = dot8<OUT>(w0, xs, cols, mm, j * 8, acc[mm]);
+                acc[mm] = dot8<OUT>(w1, xs, cols, mm, (j + 64) * 8, acc[mm]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);      // address arithmetic
+            __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);      // then every DS read of the trip
+            __builtin_amdgcn_sched_group_barrier(0x002, 400, 0);     // then the arithmetic
+        }
+#endif
+        for (; j < chunks; j += 64) {
             const Fields f = F::template fields<true>(slice + a + (j / CPB) * F::TS, (int)(j % CPB));
             uint32_t w[4];
             weights8<F, OUT>(f, w);
