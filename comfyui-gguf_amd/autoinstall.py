@@ -51,7 +51,8 @@ class _AfterOpsImport(importlib.abc.MetaPathFinder):
         else:
             return None
         loader = spec.loader
-        if loader is not None and hasattr(loader, "exec_module"):
+        # (a loader that is a CLASS -- BuiltinImporter, FrozenImporter -- is shared by every module it loads: never patched)
+        if loader is not None and not isinstance(loader, type) and hasattr(loader, "exec_module"):
             run = loader.exec_module
 
             def exec_module(module):
