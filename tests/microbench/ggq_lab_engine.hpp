@@ -34,7 +34,7 @@ GGQ_DEV void store_throttle()
 // 16 = sc1) from a wave-uniform resource whose range ends at the tensor's last byte, instead of global loads with NTL.
 // SPOL >= 0 (harness only): every store is a Window (buffer) store carrying that cache policy (same aux bits), whatever NTS says.
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          bool SKEW = false, int LPOL = -1, int SPOL = -1>
+          bool SKEW = false, int LPOL = -1, int SPOL = -1, bool DMA = false>
 struct Engine {
     static constexpr int TS = F::TS, BS = F::BS;
     static constexpr int CPB = BS / 8;                 // chunks per block
@@ -79,7 +79,18 @@ struct Engine {
             if (left < (uint64_t)GROUP_BYTES) valid = a + (uint32_t)left;
         }
         u32x4 pf[NU];
-        if constexpr (LPOL >= 0) {
+        if constexpr (DMA) {
+            // round 4: the group's bytes go global -> LDS without passing through registers (global_load_lds_dwordx4: the LDS image of one wave-instruction
+            // is lane-linear from a wave-uniform base, which is exactly the slice layout); masked lanes leave stale bytes nobody decodes
+            const uint32_t wbase = (COOP ? ((uint32_t)threadIdx.x >> 6) * 64u : 0u);
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const uint32_t o = (uint32_t)(lane + TEAM * u) * 16u;
+                if ((FULL && ALIGNED && (u + 1) * TEAM <= UNITS) || o < valid)
+                    __builtin_amdgcn_global_load_lds((const GGQ_GLOBAL void*)(base + o), (__attribute__((address_space(3))) void*)(slice + (wbase + (uint32_t)(TEAM * u)) * 16u), 16, 0, NTL ? 2 : 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (LPOL >= 0) {
             // raw buffer: units past the last one that holds valid bytes read as zero, so neither a bounds check nor a 64-bit address
             // per lane (the range is rounded up to whole units: the same < 16-byte over-read inside an aligned unit as below)
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((valid + 15u) & ~15u), 0x00020000);
@@ -97,8 +108,10 @@ struct Engine {
                 pf[u] = (o < valid) ? gload16<NTL>(base + o) : u32x4{0, 0, 0, 0};
             }
         }
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + TEAM * u) * 16) = pf[u];
+            for (int u = 0; u < NU; u++) *reinterpret_cast<u32x4*>(slice + (lane + TEAM * u) * 16) = pf[u];
+        }
         team_sync();
         const uint64_t b0 = w.lg * (uint64_t)G;
         // (NTS = false: the product's write-through Window stores, ggq_device.hpp)
@@ -206,11 +219,11 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_one(Desc d, uint64_t total
 // which leaves a 1-2 step forward scan instead of a log2(n)-step binary search -- a team holds its wave slots idle during
 // that chain, which costs the multi-wave (COOP) teams most (tests/microbench `ablocate`).
 template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int XCD = 0, bool DIRECT = false, int THR = -1, int R = 1, int ARITH = AR_F16, bool COOP = false,
-          int LPOL = -1, int SPOL = -1>
+          int LPOL = -1, int SPOL = -1, bool DMA = false>
 __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restrict__ table, uint32_t n, uint64_t total_groups, uint32_t xrun_log2,
                                                            const uint32_t* __restrict__ coarse, uint32_t coarse_shift)
 {
-    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL, SPOL>::run(total_groups, xrun_log2, [&](uint64_t g) {
+    Engine<F, G, OUT, NTL, NTS, WAVES, XCD, DIRECT, THR, R, ARITH, COOP, false, LPOL, SPOL, DMA>::run(total_groups, xrun_log2, [&](uint64_t g) {
         uint32_t lo = 0;                                // last entry with first_group <= g
         if (coarse != nullptr) {
             lo = coarse[g >> coarse_shift];

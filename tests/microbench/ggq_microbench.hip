@@ -1345,6 +1345,63 @@ static void ab_store_policy(const char* name, int qi, uint32_t xr)
     free_pool(P);
 }
 
+// ---- round 4: the group's packed bytes by LDS-DMA (global_load_lds_dwordx4) instead of global_load -> VGPR -> ds_write_b128
+template <class F, int G, int WAVES, bool COOP, bool NTL>
+static void ab_add_dma(AB& ab, const char* name, Pool& P, uint32_t xrun)
+{
+    std::vector<ggq::Desc> d = P.descs;
+    uint64_t groups = 0;
+    for (auto& x : d) { x.first_group = groups; groups += (x.n_blocks + G - 1) / G; }
+    ggq::Desc* dt; HIP_CHECK(hipMalloc(&dt, d.size() * sizeof(ggq::Desc)));
+    HIP_CHECK(hipMemcpy(dt, d.data(), d.size() * sizeof(ggq::Desc), hipMemcpyHostToDevice));
+    ab.to_free.push_back(dt);
+    const uint32_t blocks = (uint32_t)(COOP ? groups : (groups + WAVES - 1) / WAVES), n = (uint32_t)d.size();
+    // parity of this path on a small tensor with a ragged tail, against the shipped engine's output
+    bool ok = true;
+    {
+        const uint64_t nb = (uint64_t)G * 37 + 5;
+        uint8_t *dp, *o1, *o2;
+        HIP_CHECK(hipMalloc(&dp, nb * F::TS + 64)); HIP_CHECK(hipMalloc(&o1, nb * F::BS * 2)); HIP_CHECK(hipMalloc(&o2, nb * F::BS * 2));
+        HIP_CHECK(hipMemcpy(dp, P.descs[0].packed, nb * F::TS, hipMemcpyDeviceToDevice));
+        ggq::Desc one{dp, o1, nb, 0}, two{dp, o2, nb, 0};
+        ggq::Desc* t2; HIP_CHECK(hipMalloc(&t2, 2 * sizeof(ggq::Desc)));
+        HIP_CHECK(hipMemcpy(t2, &one, sizeof one, hipMemcpyHostToDevice)); HIP_CHECK(hipMemcpy(t2 + 1, &two, sizeof two, hipMemcpyHostToDevice));
+        const uint64_t g1 = (nb + G - 1) / G;
+        const uint32_t b1 = (uint32_t)(COOP ? g1 : (g1 + WAVES - 1) / WAVES);
+        hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP>), dim3(b1), dim3(WAVES * 64), 0, nullptr, t2, 1u, g1, 0u, nullptr, 0u);
+        hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, -1, -1, true>), dim3(b1), dim3(WAVES * 64), 0, nullptr, t2 + 1, 1u, g1, 0u, nullptr, 0u);
+        HIP_CHECK(hipDeviceSynchronize());
+        std::vector<uint16_t> a(nb * F::BS), b(nb * F::BS);
+        HIP_CHECK(hipMemcpy(a.data(), o1, a.size() * 2, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemcpy(b.data(), o2, b.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < a.size(); i++) ok &= a[i] == b[i];
+        HIP_CHECK(hipFree(dp)); HIP_CHECK(hipFree(o1)); HIP_CHECK(hipFree(o2)); HIP_CHECK(hipFree(t2));
+    }
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s %s G=%d waves=%d LDS-DMA staging ntl=%d xrun=%u", name, COOP ? "coop" : "solo", G, WAVES, (int)NTL, xrun);
+    ab.v.push_back(ABVariant{buf, [=] { hipLaunchKernelGGL((ggq::lab::dequant_many<F, G, ggq::OUT_F16, NTL, true, WAVES, 0, false, -1, 1, ggq::AR_F16, COOP, -1, -1, true>), dim3(blocks), dim3(WAVES * 64), 0, nullptr, dt, n, groups, xrun, nullptr, 0u); },
+                             (double)P.elements * (2.0 + (double)P.ts / P.bs), {}, ok});
+}
+
+static void ab_dma()
+{
+    { Pool P = make_pool(QTS[7], 64); printf("POOL Q4_K pairs=64\n"); AB ab;
+      ab_add<ggq::FmtQ4_K, 16, true, true, 4, 0, false, -1, 1, true>(ab, "Q4_K", P, 0, 5);
+      ab_add_dma<ggq::FmtQ4_K, 16, 4, true, true>(ab, "Q4_K", P, 5);
+      ab_add_dma<ggq::FmtQ4_K, 16, 4, true, false>(ab, "Q4_K", P, 5);
+      ab_add<ggq::FmtQ4_K, 8, true, true, 1, 0, false, -1, 1, false>(ab, "Q4_K", P, 0, 6);
+      ab_add_dma<ggq::FmtQ4_K, 8, 1, false, true>(ab, "Q4_K", P, 6);
+      ab.run(12, 4); free_pool(P); }
+    { Pool P = make_pool(QTS[4], 64); printf("POOL Q8_0 pairs=64\n"); AB ab;
+      ab_add<ggq::FmtQ8_0, 128, true, true, 4, 0, false, -1, 1, true>(ab, "Q8_0", P, 0, 5);
+      ab_add_dma<ggq::FmtQ8_0, 128, 4, true, true>(ab, "Q8_0", P, 5);
+      ab_add_dma<ggq::FmtQ8_0, 128, 4, true, false>(ab, "Q8_0", P, 5);
+      ab.run(12, 4); free_pool(P); }
+    { Pool P = make_pool(QTS[9], 64); printf("POOL Q6_K pairs=64\n"); AB ab;
+      ab_add<ggq::FmtQ6_K, 8, false, true, 1, 0, false, -1>(ab, "Q6_K", P, 4096, 6);
+      ab_add_dma<ggq::FmtQ6_K, 8, 1, false, false>(ab, "Q6_K", P, 6);
+      ab.run(12, 4); free_pool(P); }
+}
+
 static void ab_load_policy_all()
 {
     ab_load_policy<ggq::FmtQ4_K, 16, true, true>("Q4_K", 7, 5);
@@ -1387,6 +1444,7 @@ int main(int argc, char** argv)
     }
     if (what == "abq3k") ab_q3k_line_exact();
     if (what == "abdpp") ab_dpp();
+    if (what == "abdma") ab_dma();
     if (what == "abstore") { ab_store_policy<ggq::FmtQ4_K, 16, true>("Q4_K", 7, 5); ab_store_policy<ggq::FmtQ8_0, 128, true>("Q8_0", 4, 5); }
     if (what == "ceillayer") layer_ceiling();
     if (what == "ablayer4") {     // round 4: workgroup counts that divide evenly over the CUs
