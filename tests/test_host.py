@@ -694,3 +694,19 @@ def test_in_process_multi_device_placement(pkg):
         pkg.loader.gguf_sd_loader("nope.gguf", devices=["cuda:0"], device="cuda:0")
     with pytest.raises(ValueError):
         pkg.loader.gguf_sd_loader("nope.gguf", devices=[])
+
+
+def test_bench_parity_statement_is_the_min_over_ranks():
+    """bench.py: `cpu_baseline.parity_vs_gpu` of an N-rank line = every rank's verdict; one differing tensor on one rank -> MISMATCH."""
+    import bench
+    ok = [{"rank": r, "tensors": 128, "differ": 0, "first": [], "seconds": 1.0} for r in range(8)]
+    s = bench.parity_statement(ok, "bit-exact", with_reference=True)
+    assert s.startswith("bit-exact (8 x 128 = 1024 tensors on 8 ranks: every output of every rank's timed launch vs the oracle") and "rank 0's first 2 also vs the reference" in s
+    assert bench.parity_statement(ok[:1], "bit-exact", with_reference=False) == "bit-exact (128 tensors: every output of the timed launch vs the oracle)"
+    ragged = [dict(r, tensors=t) for r, t in zip(ok, (66, 69, 69, 69, 70, 70, 68, 68))]
+    assert "66 + 69 + 69 + 69 + 70 + 70 + 68 + 68 = 549 tensors on 8 ranks" in bench.parity_statement(ragged, "bit-exact")
+    bad = [dict(r) for r in ok]
+    bad[5].update(differ=1, first=[[17, "element 3 (block 0): got 1.0, expected 2.0"]])
+    s = bench.parity_statement(bad, "bit-exact")
+    assert s.startswith("MISMATCH (1 of 1024 tensors differ from the oracle on ranks [5]")
+    assert bench.parity_statement(ok, "MISMATCH").startswith("MISMATCH")                 # rank 0's check against the reference itself counts too
