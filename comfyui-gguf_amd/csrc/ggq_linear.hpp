@@ -72,6 +72,16 @@ GGQ_DEV void weights8(const Fields& f, uint32_t (&w)[4])
     }
 }
 
+// Formats whose sub-block of 32 elements (= 4 chunks = 4 consecutive lanes) has ONE (scale, min) pair decoded from the block header (get_scale_min,
+// dequant.py:129-139): the pair's two products rn(d*sc), rn(dmin*mn) are the same for the sub-block's four chunks.
+template <class F> struct SharedScale { static constexpr bool V = false; };
+template <> struct SharedScale<FmtQ4_K> { static constexpr bool V = true; };
+template <> struct SharedScale<FmtQ5_K> { static constexpr bool V = true; };
+#ifndef GGQ_LIN_SHARED_SCALE
+#define GGQ_LIN_SHARED_SCALE 1  /* Q4_K / Q5_K: lane l decodes the pair of sub-block l of a pass of 256 chunks ONCE (instead of every lane for every chunk: 22 of 62 VALU per
+                                   trip) and the chunk's lane fetches it by ds_bpermute -- the very expression of quad_f16<K_SCMN>, the same bits; 0 = generic loop; A/B builds */
+#endif
+
 #ifndef GGQ_LIN_UNROLL2
 #define GGQ_LIN_UNROLL2 0      /* A/B builds */
 #endif
@@ -134,9 +144,38 @@ __global__ __launch_bounds__(LIN_WAVES * 64) GGQ_LIN_OCC void linear_small(const
 #pragma unroll
         for (int mm = 0; mm < M; mm++) acc[mm] = 0.0f;
         uint32_t j = lane;
+        if constexpr (GGQ_LIN_SHARED_SCALE && SharedScale<F>::V) {
+            const uint32_t n_sub = cols / 32u;                               // sub-blocks per row; 8 per super-block
+            for (uint32_t c0 = 0; c0 < chunks; c0 += 256u) {                 // one pass = 256 chunks = 64 sub-blocks: lane l decodes the pair of sub-block c0 / 4 + l
+                const uint32_t sbi = (c0 >> 2) + (uint32_t)lane, sbc = sbi < n_sub ? sbi : n_sub - 1u;
+                const u32x4 hdr = *reinterpret_cast<const u32x4*>(slice + a + (sbc >> 3) * F::TS);       // [d][dmin][scales 12]
+                int32_t sc, mn;
+                k_scale_min(hdr, (int)(sbc & 7u), sc, mn);
+                const uint32_t pre = as_u32(as_h2(hdr.x) * ints_h2((uint32_t)sc | ((uint32_t)mn << 16), 0.0f));    // (rn(d*sc), rn(dmin*mn)): quad_f16<K_SCMN>'s own expression
+#pragma unroll
+                for (uint32_t it = 0; it < 4u; it++) {
+                    if (c0 + 64u * it >= chunks) break;                      // wave-uniform
+                    // chunk jj belongs to sub-block jj / 4 = c0 / 4 + 16 it + lane / 4: its pair sits in lane 16 it + lane / 4 (every lane takes part in the exchange)
+                    const h2 dlml = as_h2((uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u * it + ((uint32_t)lane >> 2)) << 2), (int)pre));
+                    const uint32_t jj = c0 + 64u * it + (uint32_t)lane;
+                    if (jj < chunks) {
+                        const h2 dl = bcast_lo(dlml), ml = bcast_hi(dlml);
+                        const Fields f = F::template fields<true>(slice + a + (jj / CPB) * F::TS, (int)(jj % CPB));   // only the quants are used: its scale decode is dead code
+                        const H2x2 q0 = fields_h2(f.t0, (float)F::BIAS), q1 = fields_h2(f.t1, (float)F::BIAS);
+                        uint32_t w[4] = {as_u32(dl * q0.a - ml), as_u32(dl * q0.b - ml), as_u32(dl * q1.a - ml), as_u32(dl * q1.b - ml)};
+                        if constexpr (OUT == OUT_BF16) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) w[k] = h2_to_bf16x2(w[k]);
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < M; mm++) acc[mm] = dot8<OUT>(w, xs, cols, mm, jj * 8, acc[mm]);
+                    }
+                }
+            }
+            j = chunks;                                                      // nothing left for the generic loop
+        }
 #if GGQ_LIN_UNROLL2
-        // two chunks per trip, every LDS read of both issued before the arithmetic of either: a trip's three dependent LDS round trips (block header,
-        // quants, x) otherwise sit back to back behind s_waitcnt lgkmcnt(0) -- the loop is latency-, not VALU-bound (62 VALU = 124 issue cycles per chunk)
+        // two chunks per trip, every LDS read of both issued before the arithmetic of either (A/B builds; EXPERIMENTS.md R4-6: mixed, not taken)
         for (; j + 64 < chunks; j += 128) {
             const Fields f0 = F::template fields<true>(slice + a + (j / CPB) * F::TS, (int)(j % CPB));
             const Fields f1 = F::template fields<true>(slice + a + ((j + 64) / CPB) * F::TS, (int)((j + 64) % CPB));
@@ -148,9 +187,6 @@ __global__ __launch_bounds__(LIN_WAVES * 64) GGQ_LIN_OCC void linear_small(const
                 acc[mm] = dot8<OUT>(w0, xs, cols, mm, j * 8, acc[mm]);
                 acc[mm] = dot8<OUT>(w1, xs, cols, mm, (j + 64) * 8, acc[mm]);
             }
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);      // address arithmetic
-            __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);      // then every DS read of the trip
-            __builtin_amdgcn_sched_group_barrier(0x002, 400, 0);     // then the arithmetic
         }
 #endif
         for (; j < chunks; j += 64) {

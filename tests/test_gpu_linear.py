@@ -128,3 +128,31 @@ def test_install_fused_small_m_wraps_the_linear_forward(pkg):
         owner, name, fn = record
         setattr(owner, name, fn)
     assert Linear.forward_ggml_cast_weights is original
+
+
+@pytest.mark.parametrize("name", ["Q4_K", "Q5_K", "Q8_0", "Q3_K"])
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f32"])
+def test_fused_linear_exact_arithmetic_is_bit_equal(pkg, name, kind):
+    """Scales 2^-8 and integer activations: every weight, product and fp32 partial sum is exact in any order, so the kernel must return THE
+    correctly rounded value -- any weight that is not the reference's (a scale pair taken from the wrong sub-block by the Q4_K / Q5_K
+    lane exchange, say) shows as a wrong multiple of 2^-8.  Row lengths cover a single partial pass of the exchange (256 columns = 32
+    chunks), whole passes (8192 = 4 passes) and ragged ones (2304 = 1 pass + half a trip; 3072 = 1.5 passes)."""
+    q = pkg.qtypes.Q[name]
+    dtype, _ = DT[kind]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    bs, ts = pkg.qtypes.block_geometry(q)
+    long_row = 8192 if 8192 // bs * ts <= 6000 else 4096                        # a row's packed bytes must fit a wave's LDS slice (Q8_0: 4096 columns)
+    for rows, cols, m in ((33, 256, 1), (50, 2304, 2), (41, 3072, 4), (9, long_row, 3)):
+        blocks = pkg.synth.make_blocks(q, rows * cols // bs, seed=cols + m, mode="raw")
+        for off in pkg.qtypes.SCALE_FIELDS[q]:
+            blocks[:, off], blocks[:, off + 1] = 0x00, 0x1C                       # fp16 0x1C00 = 2^-8
+        blocks = blocks.reshape(-1)
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        w64 = _dense_weight(q, blocks, kind, rows, cols)
+        assert np.all(w64 * 2.0 ** 8 == np.round(w64 * 2.0 ** 8))
+        x = torch.randint(-2, 3, (m, cols), device=DEV, generator=g).to(dtype)
+        x64 = x.double().cpu().numpy()
+        assert (np.abs(x64) @ np.abs(w64).T).max() < 2.0 ** 16                   # every partial sum a multiple of 2^-8 below 2^16: exact in fp32
+        want = torch.from_numpy(x64 @ w64.T).to(dtype)
+        got = pkg.fused.linear_small(x, w)
+        assert torch.equal(got.cpu(), want), (name, kind, rows, cols, m)
