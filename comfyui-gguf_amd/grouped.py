@@ -152,14 +152,20 @@ class ShardedPlan:
         return flat
 
     def launch(self):
-        """Enqueue every shard's kernels from the calling thread; returns at once (nothing is synchronised)."""
+        """Enqueue every shard's kernels from the calling thread; returns at once (the host waits for nothing).  With ``own_streams`` every
+        shard runs on its own stream -- ordered after its device's current stream, and that current stream is then made to wait for the shard
+        (a GPU-side dependency): the outputs may be consumed on the current stream as after ``DequantPlan.launch``, while shards that share
+        a device still overlap each other."""
         for k, p in enumerate(self.plans):
             if self.streams is None:
                 p.launch()
             else:
-                s = self.streams[k]
-                s.wait_stream(torch.cuda.current_stream(p.device))
+                s, cur = self.streams[k], torch.cuda.current_stream(p.device)
+                s.wait_stream(cur)
                 p.launch(s)
+        if self.streams is not None:
+            for s, p in zip(self.streams, self.plans):
+                torch.cuda.current_stream(p.device).wait_stream(s)
         return self.outputs
 
     def synchronize(self):

@@ -28,8 +28,11 @@ def test_sharded_plan_two_shards_two_streams_vs_oracle(pkg, dtype):
     assert plan.bytes == sum(pkg.sharding.tensor_cost(e) for e in manifest)
     for _ in range(3):
         plan.launch()
+    # consumed on the CURRENT stream without any host-side wait: launch() made it depend on the shard streams
+    sums = [o.view(torch.int16).to(torch.int64).sum() for o in plan.outputs_in_order()]
     plan.synchronize()
     outs = plan.outputs_in_order()
+    assert [int(s) for s in sums] == [int(o.view(torch.int16).to(torch.int64).sum()) for o in outs]
     assert [tuple(o.shape) for o in outs] == [tuple(s) for _, _, s in manifest]
     n, bad = plan_check.check_plan([it[0] for it in items], [q for _, q, _ in manifest], outs)
     assert n == len(manifest) and not bad, bad[:3]
