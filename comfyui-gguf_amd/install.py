@@ -40,6 +40,9 @@ kernel launch per K layers instead of K (lookahead.DequantAhead; a dependent ker
 launch cannot overlap its reads with its writes).  Same kernels, same bits, fresh tensors; opt-in because up to K - 1 dense weights are
 alive ahead of their use (VRAM the reference's estimate does not see).
 
+``fast`` (or ``GGQ_FAST=1``): ``fused_small_m`` + ``fused_mfma`` + ``gather_embedding`` in one switch -- the opt-ins that hold no VRAM and measured faster
+wherever they apply.
+
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
 overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
 and unpacked on a side stream while the current layer's GEMM runs (``overlap="all"``: also for weights already in HBM, where it
@@ -56,10 +59,20 @@ _installed = {}
 
 
 def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
-            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, lookahead=None):
-    """Patch the reference modules in place; returns the dict of original functions."""
+            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, lookahead=None, fast=None):
+    """Patch the reference modules in place; returns the dict of original functions.
+
+    ``fast`` (or ``GGQ_FAST=1``; needs ``ref_ops``): the three opt-ins that hold no VRAM and measured faster wherever they apply, in one switch --
+    ``fused_small_m`` + ``fused_mfma`` (same weights, results equal to F.linear up to fp32 summation order) + ``gather_embedding`` (bit-identical).
+    An option given explicitly (argument or its own environment variable) wins over the switch."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
+    if fast is None:
+        fast = os.environ.get("GGQ_FAST", "0") not in ("", "0")
+    if fast and ref_ops is not None:
+        fused_small_m = True if fused_small_m is None and "GGQ_FUSED_SMALL_M" not in os.environ else fused_small_m
+        fused_mfma = True if fused_mfma is None and "GGQ_FUSED_MFMA" not in os.environ else fused_mfma
+        gather_embedding = True if gather_embedding is None and "GGQ_GATHER_EMBEDDING" not in os.environ else gather_embedding
     from . import _native
     _native.lib()                                   # fail now, loudly, if the extension is absent
     orig = {"dequantize": ref_dequant.dequantize, "dequantize_tensor": ref_dequant.dequantize_tensor}
@@ -162,7 +175,7 @@ def describe(ref_dequant):
 
 _SMALL_M_HINT = ("comfyui-gguf_amd: this model runs quantized linears on inputs of <= 4 rows (modulation layers): each call unpacks the whole weight for a "
                  "GEMV (about 3 ms per FLUX.1-dev step).  GGQ_FUSED_SMALL_M=1 (install(fused_small_m=True)) fuses them -- results equal to F.linear "
-                 "up to fp32 summation order instead of bit for bit, which is why it is not the default.")
+                 "up to fp32 summation order instead of bit for bit, which is why it is not the default.  GGQ_FAST=1 turns on every such option at once.")
 
 
 def _recommend_small_m(linear_cls, probe_calls=4096):

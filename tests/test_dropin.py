@@ -124,3 +124,19 @@ def test_small_m_recommendation_is_logged_once_and_removes_itself(custom_nodes, 
     assert sum("GGQ_FUSED_SMALL_M=1" in r.getMessage() for r in caplog.records) == 1
     assert torch.equal(torch.Tensor(y), lin(x))
     amd_mod.install.uninstall(sys.modules[ref_mod.__name__ + ".dequant"])
+
+
+def test_ggq_fast_switch_turns_on_the_no_vram_opt_ins(custom_nodes, monkeypatch, caplog):
+    """GGQ_FAST=1: fused_small_m + fused_mfma + gather_embedding in one switch; an option's own variable still wins."""
+    ref_dir, amd_dir = custom_nodes
+    monkeypatch.setenv("GGQ_FAST", "1")
+    monkeypatch.setenv("GGQ_GATHER_EMBEDDING", "0")
+    ref_mod = _comfy_load_custom_node(ref_dir)
+    with caplog.at_level(logging.INFO, logger="comfyui-gguf_amd"):
+        amd_mod = _comfy_load_custom_node(amd_dir)
+    ro, rd = sys.modules[ref_mod.__name__ + ".ops"], sys.modules[ref_mod.__name__ + ".dequant"]
+    assert hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__")
+    assert not hasattr(ro.GGMLOps.Embedding.forward_ggml_cast_weights, "__wrapped__")             # GGQ_GATHER_EMBEDDING=0 wins
+    assert "fused_small_m=True" in caplog.text and "fused_mfma=256" in caplog.text and "gather_embedding" not in caplog.text
+    amd_mod.install.uninstall(rd)
+    assert not hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__")
