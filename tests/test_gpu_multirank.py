@@ -29,7 +29,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(nproc, script_args, timeout=600, backend="gloo"):
+def _run(nproc, script_args, timeout=1500, backend="gloo"):
     env = dict(os.environ, GGQ_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", GGQ_BENCH_RCCL_TIMEOUT_S="120")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
