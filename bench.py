@@ -192,6 +192,66 @@ def timed_steps(plan, steps, warmup, device, fence):
     return start.elapsed_time(stop), wall_ms
 
 
+_CEILING = {}
+
+
+def measured_ceiling(pkg, device, gib=2, reps=7):
+    """What THIS box's memory system gives streams with no arithmetic, measured in this process by the product library's own probes
+    (include/ggq.h ggq_calibrate: 16 B per lane, 1 KiB per wave instruction like the dequant kernels): a fill, a copy and a read over
+    ``gib`` GiB (8x the 256 MiB Infinity Cache), plain and non-temporal, HIP events on the launch stream, median of ``reps`` launches after
+    one warm-up; the better of plain / non-temporal counts.  Cached per device: the headline and the sub-lines quote the same figures."""
+    key = str(device)
+    if key in _CEILING:
+        return _CEILING[key]
+    nat = pkg._native
+    L = nat.lib()
+    n = gib << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    src.view(torch.int64).random_()
+    stream = torch.cuda.current_stream(device)
+    out = {}
+    with torch.cuda.device(device):
+        for name, kind, moved in (("fill", nat.CAL_FILL, n), ("fill_nt", nat.CAL_FILL_NT, n), ("copy", nat.CAL_COPY, 2 * n), ("copy_nt", nat.CAL_COPY_NT, 2 * n),
+                                  ("read", nat.CAL_READ, n)):
+            ts = []
+            for i in range(reps + 1):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                nat.check(L.ggq_calibrate(kind, src.data_ptr(), dst.data_ptr(), n, stream.cuda_stream), "ggq_calibrate")
+                b.record(stream)
+                torch.cuda.synchronize(device)
+                if i:
+                    ts.append(a.elapsed_time(b))
+            ts.sort()
+            out[name] = round(moved / (ts[len(ts) // 2] * 1e-3) / 1e9, 1)
+    del src, dst
+    torch.cuda.empty_cache()
+    res = {"measured_fill_GBps": max(out["fill"], out["fill_nt"]), "measured_copy_GBps": max(out["copy"], out["copy_nt"]), "measured_read_GBps": out["read"],
+           "measured_all_GBps": out,
+           "measured_how": f"ggq_calibrate over {gib} GiB in this process, median of {reps} launches (HIP events); copy counts read + written bytes"}
+    _CEILING[key] = res
+    return res
+
+
+def with_ceiling(roofline, ceiling, read_bytes, write_bytes):
+    """Add the measured figures and the ceiling of a stream with THIS kernel's read : write mix to a roofline object.  The mix is split into a
+    copy part (every read byte paired with a written byte, at the measured copy rate) and a fill part (the remaining written bytes, at the
+    measured fill rate): blend = (r + w) / (2r / copy + (w - r) / fill).  frac_of_blend = achieved / blend: how much of what this memory system
+    gives a stream of that mix the kernel reaches -- beside frac, which stays against the 8 TB/s spec peak."""
+    if not ceiling:
+        return roofline
+    r, w = float(read_bytes), float(write_bytes)
+    copy, fill, read = ceiling["measured_copy_GBps"], ceiling["measured_fill_GBps"], ceiling["measured_read_GBps"]
+    t = (2 * min(r, w) / copy + (w - r) / fill) if w >= r else (2 * w / copy + (r - w) / read)
+    blend = (r + w) / t
+    roofline.update({k: ceiling[k] for k in ("measured_fill_GBps", "measured_copy_GBps", "measured_read_GBps")})
+    roofline.update({"blend_ceiling_GBps": round(blend, 1), "frac_of_blend": round(roofline["achieved"] / blend, 4),
+                     "blend_mix": {"read_share": round(r / (r + w), 4), "write_share": round(w / (r + w), 4)},
+                     "blend_how": "copy part (2 x read bytes at measured copy rate) + fill part (write - read bytes at measured fill rate); " + ceiling["measured_how"]})
+    return roofline
+
+
 def per_launch_stats(plan, reps, device):
     """Median / min duration of single launches (one HIP-event pair per launch, same stream) -- the
     distribution behind the average the timed region reports (median and min)."""
@@ -261,7 +321,14 @@ def cpu_baseline_reference(pkg, plan, qtypes, budget_s):
     finally:
         torch.set_num_threads(default_threads)
     med, tmin, reps, threads = best
-    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "reference",
+    medians = [v["median_GBps"] for v in by_threads.values()]
+    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "threads": threads, "host_cpus": os.cpu_count(), "kind": "reference",
+            # the reference's CPU path allocates every intermediate of its op chain afresh: it is bound by page faults, not by arithmetic or DRAM,
+            # and the same function on the same host swings by up to 10x between tensor sizes, thread counts and passes
+            "range_GBps": {"lowest_median_over_thread_counts": min(medians), "highest_median_over_thread_counts": max(medians),
+                           "best_single_pass": max(v["min_GBps"] for v in by_threads.values())},
+            "note": "a range, not a point: the reference's torch-CPU path is page-fault-bound on its freshly allocated intermediates; value = the best median; "
+                    "cores = threads = torch intra-op threads of that median, host_cpus = CPUs the host shows",
             "sample": (f"reference dequant.py:30 dequantize() verbatim ({reference.source()} copy) on torch-CPU, best of {counts} intra-op threads "
                        f"(torch default {default_threads}; {os.cpu_count()} host CPUs visible); {' + '.join(f'{q.name} {sh[0]}x{sh[1]}' for q, sh in zip(qs, shapes))} "
                        f"(same packed bytes the GPU read), {reps} passes after 3 warm-up, median; (in+out) bytes / time"),
@@ -340,7 +407,7 @@ def cpu_baseline_port(pkg, plan, qtype, budget_s):
             best = (med, c, reps, tmin)
     med, threads, reps, tmin = best
     leg = "oracle/ggq_oracle_simd.c (AVX2+F16C)" if simd else "oracle/ggq_oracle.c (soft-float; host lacks AVX2/F16C)"
-    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+    return {"value": round(nbytes / med / 1e9, 3), "unit": "GB/s", "cores": threads, "threads": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": (f"{qtype.name}: first {n_sample} pool tensors ({sum(o.size for o in outs)} elements, same packed bytes), "
                        f"{reps} passes of {leg} with OpenMP on {threads} threads (best of team sizes {counts}; "
                        f"{os.cpu_count()} host CPUs visible), median; fastest pass {nbytes / tmin / 1e9:.3f} GB/s"),
@@ -454,6 +521,9 @@ def run_flux(pkg, args, W, workload=None, cpu_seconds=None):
                          "host_wall_ms_per_step": round(wall_ms_step, 5), "of": "rank 0's shard"},
             "cpu_baseline": None,
         }
+        if not args.no_ceiling:
+            in_b = sum(t.numel() for t in plan._keep)
+            with_ceiling(result["roofline"], measured_ceiling(pkg, W.device), in_b, plan.bytes - in_b)
     if cpu_seconds > 0:
         base, port = cpu_baselines(pkg, plan, [q for _, q, _ in mine], cpu_seconds, W)
         if rank == 0:
@@ -700,18 +770,6 @@ def run_per_layer(pkg, args, device, fence):
             dq(t, dtype)
 
     (e_ms, e_host), eager_regions = median(eager_pass, passes)
-    # the same eager loop with the opt-in lookahead (lookahead.DequantAhead, depth 4): one launch per 4 layers
-    ahead = pkg.lookahead.DequantAhead(4, dq)
-
-    def ahead_pass():
-        for t in tensors:
-            ahead(t, dtype)
-
-    (a_ms, _), _ = median(ahead_pass, passes)
-    ahead_stats = ahead.stats()
-    ahead.clear()
-    del ahead
-
     from oracle import plan_check
     standalone, parity = {}, None
     for policy, fn in (("shipped_sc1", dq), ("streaming_nt", dq_stream)):
@@ -799,7 +857,7 @@ def run_per_layer(pkg, args, device, fence):
         torch.cuda.empty_cache()
 
     g = standalone["shipped_sc1"]
-    return {
+    line = {
         "metric": "dequant GB/s, one dequantize_tensor() launch per layer (packed in -> bf16 out), (in+out) bytes / time",
         "value": g["GBps"], "unit": "GB/s", "ms_per_step": g["ms_per_pass"],
         "config": {"workload": f"FLUX.1-dev weight set ({len(manifest)} tensors, {args.mix}) through the per-layer entry point, one launch per tensor in model "
@@ -809,9 +867,6 @@ def run_per_layer(pkg, args, device, fence):
                    "standalone_gpu_bound": standalone,
                    "eager_regions_ms": eager_regions, "eager_ms_per_pass": round(e_ms, 5), "eager_GBps": round(nbytes / (e_ms * 1e-3) / 1e9, 1),
                    "eager_host_enqueue_us_per_call": round(e_host * 1e3 / len(manifest), 2),
-                   "eager_with_lookahead4": {"ms_per_pass": round(a_ms, 5), "GBps": round(nbytes / (a_ms * 1e-3) / 1e9, 1),
-                                             "launches": ahead_stats["launches"], "hits": ahead_stats["hits"],
-                                             "note": "opt-in install(lookahead=4): the same tensors, one ggq_dequant_batch launch per 4 layers"},
                    "in_context": ctx,
                    "reference_on_this_gpu": ref_gpu,
                    "parity_vs_oracle": parity},
@@ -821,6 +876,10 @@ def run_per_layer(pkg, args, device, fence):
                      "with_streaming_stores": {"achieved": standalone["streaming_nt"]["GBps"], "frac": round(standalone["streaming_nt"]["GBps"] / HBM_PEAK_GBS, 4)}},
         "cpu_baseline": None,
     }
+    if not args.no_ceiling:
+        out_b = 2 * sum(sh[0] * sh[1] for _, _, sh in manifest)          # bf16 results
+        with_ceiling(line["roofline"], measured_ceiling(pkg, device), nbytes - out_b, out_b)
+    return line
 
 
 def median_region(pkg, plan, args, W, regions, steps=None, warmup=None):
@@ -849,6 +908,7 @@ def main():
     ap.add_argument("--no-per-mode", action="store_true", help="skip the (dequant_dtype, dtype) table of the headline format")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the cpu_baseline legs (0 = skip)")
     ap.add_argument("--regions", type=int, default=3, help="timed regions of K steps each; the median region is reported")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the measured fill / copy / read ceilings (ggq_calibrate) beside the spec peak")
     ap.add_argument("--no-workloads", action="store_true", help="skip the configs[3] / configs[4] sub-lines of the default run")
     ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
@@ -963,6 +1023,8 @@ def main():
                          "avg_launch_ms": round(gpu_ms_step, 5), "median_launch_ms": round(med_ms, 5), "min_launch_ms": round(min_ms, 5),
                          "host_wall_ms_per_step": round(wall_ms_step, 5)},
         }
+        if not args.no_ceiling:
+            with_ceiling(result["roofline"], measured_ceiling(pkg, device), in_bytes, bytes_rank - in_bytes)
         if world > 1:
             result["config"]["shards"], result["config"]["shard_cover"] = shards, cover
             result["roofline"]["of"] = "rank 0's GPU"

@@ -14,7 +14,6 @@ fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
     resident    opt-in cache that keeps dequantized weights resident in HBM (288 GB make it possible)
     fused       opt-in fused dequantize + linear for inputs of one to four rows (modulation layers)
     overlap     opt-in side-stream prefetch: layer i+1's (host->device copy and) unpack under layer i's GEMM
-    lookahead   opt-in: the next layers' unpacks ride in the launch of the one that was asked for (one launch per K layers)
     sharding    tensor-list partitioning for one-process-per-GPU runs (no collectives)
     ops         GGMLTensor / GGMLLinear stand-ins for driving the path without ComfyUI
     manifests   synthetic weight manifests of the BASELINE.json configurations
@@ -29,7 +28,7 @@ __version__ = "0.1.0"
 # package adds NO nodes -- it accelerates the ones ComfyUI-GGUF registers ("Unet Loader (GGUF)" & co. keep working unchanged).
 NODE_CLASS_MAPPINGS = {}
 NODE_DISPLAY_NAME_MAPPINGS = {}
-_LAZY = ("_native", "autoinstall", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap", "lookahead")
+_LAZY = ("_native", "autoinstall", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap")
 
 
 def _running_under_comfyui():

@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -31,7 +31,7 @@ _FMA_RE = re.compile(r"\b(v_(?:pk_)?(?:fma|fmac)_\w+|v_mad_(?:f16|f32|legacy_f\w
 
 GGQ_OK, GGQ_ERR_QTYPE, GGQ_ERR_ALIGN, GGQ_ERR_ARG, GGQ_ERR_HIP, GGQ_ERR_NOMEM, GGQ_ERR_IO, GGQ_ERR_FORMAT = range(8)
 F16, BF16, F32 = 0, 1, 2          # ggq_dtype: compute and out dtypes
-BATCH_MAX = 32                    # GGQ_BATCH_MAX (include/ggq.h): tensors per ggq_dequant_batch call
+CAL_FILL, CAL_FILL_NT, CAL_COPY, CAL_COPY_NT, CAL_READ = range(5)      # ggq_cal_kind
 OUT_F16, OUT_BF16, OUT_F32 = F16, BF16, F32
 
 # every symbol include/ggq.h declares: name -> (restype, argtypes)
@@ -71,7 +71,7 @@ SYMBOLS = {
     "ggq_dequant": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_stream": (_int, [_int, _vp, _u64, _vp, _int, _int, _vp]),
     "ggq_dequant_f16": (_int, [_int, _vp, _u64, _vp, _vp]),
-    "ggq_dequant_batch": (_int, [ctypes.POINTER(ggq_desc), _u32, _vp]),
+    "ggq_calibrate": (_int, [_int, _vp, _vp, _u64, _vp]),
     "ggq_plan_create": (_int, [ctypes.POINTER(ggq_desc), _u32, ctypes.POINTER(_vp)]),
     "ggq_plan_launch": (_int, [_vp, _vp]),
     "ggq_plan_bytes": (_u64, [_vp]),

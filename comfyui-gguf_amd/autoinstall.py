@@ -11,8 +11,10 @@ import importlib.abc
 import logging
 import sys
 
+import os
+
 log = logging.getLogger("comfyui-gguf_amd")
-_state = {"armed": False, "installed": None}
+_state = {"armed": False, "installed": None, "gave_up": False}
 
 
 def _is_ref_ops(mod):
@@ -21,8 +23,9 @@ def _is_ref_ops(mod):
 
 def _install_over(ops_mod):
     """``ops_mod`` = the reference's ops module, fully executed (so its ``.dequant`` sibling exists).  Never raises into the
-    reference's import: a failure is logged with its traceback and the reference keeps its own torch path."""
-    if _state["installed"] is not None:
+    reference's import: a failure is logged ONCE with its traceback, the reference keeps its own torch path, and this package stops
+    trying (``gave_up``: a second ``*.ops`` import must not retry and log again)."""
+    if _state["installed"] is not None or _state["gave_up"]:
         return
     pkg = ops_mod.__name__.rsplit(".", 1)[0]
     deq = sys.modules.get(pkg + ".dequant")
@@ -34,15 +37,54 @@ def _install_over(ops_mod):
         _state["installed"] = pkg
         log.info("comfyui-gguf_amd: MI355X HIP dequant path installed over %s (dequantize, dequantize_tensor%s)", pkg, inst.describe(deq))
     except Exception:                                      # noqa: BLE001 -- see docstring
+        _state["gave_up"] = True
         log.exception("comfyui-gguf_amd: could not install over %s; the reference's torch path stays in place", pkg)
+
+
+def _may_be_reference_ops(fullname):
+    """Cheap test BEFORE any other finder is consulted: ``<package>.ops`` where <package> is already imported and has a ``dequant``
+    sibling (imported, or a dequant.py in its directory).  torchvision.ops, comfy.ops & co. fail it and pass through untouched."""
+    parent = fullname[:-len(".ops")]
+    if parent + ".dequant" in sys.modules:
+        return True
+    pkg = sys.modules.get(parent)
+    for d in getattr(pkg, "__path__", None) or ():
+        if os.path.isfile(os.path.join(d, "dequant.py")):
+            return True
+    return False
+
+
+class _HookedLoader(importlib.abc.Loader):
+    """Proxy of the loader the regular finders chose for ``<package>.ops``: same module creation and execution, then ``after(module)``.
+    The real loader object is left untouched (round 4 rebound ``exec_module`` on the loader instance itself)."""
+
+    def __init__(self, loader, after):
+        self._loader, self._after = loader, after
+
+    def create_module(self, spec):
+        return self._loader.create_module(spec)
+
+    def exec_module(self, module):
+        self._loader.exec_module(module)
+        self._after(module)
+
+    def __getattr__(self, name):                           # get_code / get_source / get_filename / is_package / ... of the real loader
+        return getattr(self._loader, name)
 
 
 class _AfterOpsImport(importlib.abc.MetaPathFinder):
     """One-shot post-import hook: lets the regular finders locate ``<package>.ops``, then runs ``_install_over`` right after the
-    module body has executed (its loader's ``exec_module`` is wrapped on that one spec).  Removes itself once it has installed."""
+    module body has executed (the spec's loader is wrapped in a proxy).  Removes itself once it has installed -- or given up."""
+
+    def _retire(self):
+        if self in sys.meta_path:
+            sys.meta_path.remove(self)
 
     def find_spec(self, fullname, path, target=None):
-        if not fullname.endswith(".ops") or _state["installed"] is not None:
+        if _state["installed"] is not None or _state["gave_up"]:
+            self._retire()
+            return None
+        if not fullname.endswith(".ops") or not _may_be_reference_ops(fullname):
             return None
         for finder in sys.meta_path:
             spec = finder.find_spec(fullname, path, target) if finder is not self and hasattr(finder, "find_spec") else None
@@ -51,17 +93,13 @@ class _AfterOpsImport(importlib.abc.MetaPathFinder):
         else:
             return None
         loader = spec.loader
-        # (a loader that is a CLASS -- BuiltinImporter, FrozenImporter -- is shared by every module it loads: never patched)
-        if loader is not None and not isinstance(loader, type) and hasattr(loader, "exec_module"):
-            run = loader.exec_module
-
-            def exec_module(module):
-                run(module)
+        if loader is not None and hasattr(loader, "exec_module"):
+            def after(module):
                 if _is_ref_ops(module):
                     _install_over(module)
-                    if _state["installed"] is not None and self in sys.meta_path:
-                        sys.meta_path.remove(self)
-            loader.exec_module = exec_module
+                    if _state["installed"] is not None or _state["gave_up"]:
+                        self._retire()
+            spec.loader = _HookedLoader(loader, after)
         return spec
 
 
@@ -76,7 +114,7 @@ def arm():
     for mod in list(sys.modules.values()):
         if mod is not None and getattr(mod, "__name__", "").endswith(".ops") and _is_ref_ops(mod):
             _install_over(mod)
-            if _state["installed"] is not None:
+            if _state["installed"] is not None or _state["gave_up"]:
                 return _state["installed"]
     sys.meta_path.insert(0, _AfterOpsImport())
     return None

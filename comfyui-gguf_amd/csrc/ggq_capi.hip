@@ -42,7 +42,9 @@ using namespace ggq;
 template <class F> struct PadOf { static constexpr uint32_t V = 0; };
 template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };
 template <class F> struct PlainLoads { static constexpr bool V = false; };    // non-temporal loads cost these three 2-4 %
+#ifndef GGQ_Q2K_NT_LOADS    /* A/B builds define it */
 template <> struct PlainLoads<FmtQ2_K> { static constexpr bool V = true; };
+#endif
 template <> struct PlainLoads<FmtQ3_K> { static constexpr bool V = true; };
 template <> struct PlainLoads<FmtQ6_K> { static constexpr bool V = true; };
 template <class F> struct TuneSolo {             // one-wave teams x 2048 elements, runs of 64 groups
@@ -89,6 +91,9 @@ template <class F> struct Tune : TuneCoop<F> {};
 //       format      G   coop  waves  log2(run)
 GGQ_TUNE(FmtQ3_K,    8,  false, 1,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    6);
+#ifdef GGQ_Q2K_G32          /* A/B builds only: Q2_K teams of 4 waves x 8192 elements on whole-model launches too; the value is log2(run) */
+GGQ_TUNE(FmtQ2_K,    32, true,  4,    GGQ_Q2K_G32);
+#endif
 #undef GGQ_TUNE
 
 // The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
@@ -122,9 +127,13 @@ template <> struct CoopForOut<FmtIQ4_XS, OUT_BF16> { static constexpr bool V = f
 // Q8_0 / Q4_1 -- and the cells where an all-coop against an all-solo build, alternated twice on one box over all 12 x 9 cells
 // (profiles/r01_mode_table_all_coop_vs_all_solo.json), says otherwise by more than 1.5 % in both alternations:
 template <class F, int ARITH, int OUT> struct UseCoop {
+#ifdef GGQ_F32_COOP_ALL     /* A/B builds only: workgroup teams for every fp32-output cell */
+    static constexpr bool V = OUT == OUT_F32 || ((ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V);
+#else
     static constexpr bool V = (ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V;
+#endif
 };
-#if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES)
+#if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES) && !defined(GGQ_F32_COOP_ALL)
 #define GGQ_TEAM(F, AR, OUT_, COOP_) template <> struct UseCoop<F, AR, OUT_> { static constexpr bool V = COOP_; }
 GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F16, false);     // coop -4.1 %  (bf16 arithmetic: -1.1 % with the other two outputs, taken along)
 GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_BF16, false);
@@ -169,7 +178,6 @@ constexpr uint64_t MAX_GRID = 0x7FFFFFFFull;
 typedef hipError_t (*one_fn)(const Desc&, hipStream_t, bool);
 typedef hipError_t (*many_fn)(const Desc*, uint32_t, uint64_t, const uint32_t*, uint32_t, hipStream_t);
 typedef hipError_t (*rows_fn)(const void*, const int64_t*, void*, uint64_t, uint32_t, uint64_t, hipStream_t);
-typedef hipError_t (*few_fn)(const Few&, uint32_t, uint64_t, hipStream_t);
 
 // Single tensors of layer size (per-layer calls, ops.py:177; rocprof kernel times of 3072x3072 / 3072x12288 tensors, solo vs coop
 // builds): the coop shape is 3-8 % FASTER for the 4/5-bit formats (Q4_K 6.10 vs 6.61 us, 17.7 vs 18.1 us) but 3-8 % SLOWER for
@@ -242,20 +250,6 @@ hipError_t run_many(const Desc* table, uint32_t n, uint64_t groups, const uint32
     return hipGetLastError();
 }
 
-// a few tensors, descriptors by value: the whole-model team shape (the batch is several layers: 50-250 M elements)
-template <class F, int ARITH, int OUT>
-hipError_t run_few(const Few& few, uint32_t n, uint64_t groups, hipStream_t s)
-{
-    using T = TuneFor<F, ARITH, OUT>;
-    if (groups == 0) return hipSuccess;
-    const uint64_t blocks = T::COOP ? groups : (groups + T::WAVES - 1) / T::WAVES;
-    if (blocks > MAX_GRID) return hipErrorInvalidConfiguration;
-    // (sc1 stores, like the single-tensor launches: these weights are read by the next few GEMMs)
-    hipLaunchKernelGGL((dequant_few<F, T::G, OUT, T::NTL, false, T::WAVES, ARITH, T::COOP>), dim3((uint32_t)blocks), dim3(T::WAVES * 64), lds_pad_for<F>(), s, few, n, groups,
-                       xrun_of<T, F>(groups));
-    return hipGetLastError();
-}
-
 // the embedding lookup: a few hundred rows of one table per call -- one-wave teams, plain loads (a token may repeat)
 template <class F, int ARITH, int OUT>
 hipError_t run_rows(const void* packed, const int64_t* indices, void* out, uint64_t n_rows, uint32_t row_blocks, uint64_t n_indices, hipStream_t s)
@@ -280,7 +274,6 @@ struct FormatEntry {
     one_fn one[3][3];      // [compute dtype][out dtype]
     many_fn many[3][3];
     rows_fn rows[3][3];
-    few_fn few[3][3];
 };
 
 #define GGQ_ROW(FN, F, AR) {FN<F, AR, OUT_F16>, FN<F, AR, OUT_BF16>, FN<F, AR, OUT_F32>}
@@ -290,8 +283,7 @@ struct FormatEntry {
         F::ID, F::BS, F::TS, {GGQ_GROUPS(F, AR_F16), GGQ_GROUPS(F, AR_BF16), GGQ_GROUPS(F, AR_F32)},     \
         {GGQ_ROW(run_one, F, AR_F16), GGQ_ROW(run_one, F, AR_BF16), GGQ_ROW(run_one, F, AR_F32)},      \
         {GGQ_ROW(run_many, F, AR_F16), GGQ_ROW(run_many, F, AR_BF16), GGQ_ROW(run_many, F, AR_F32)},   \
-        {GGQ_ROW(run_rows, F, AR_F16), GGQ_ROW(run_rows, F, AR_BF16), GGQ_ROW(run_rows, F, AR_F32)},   \
-        {GGQ_ROW(run_few, F, AR_F16), GGQ_ROW(run_few, F, AR_BF16), GGQ_ROW(run_few, F, AR_F32)}       \
+        {GGQ_ROW(run_rows, F, AR_F16), GGQ_ROW(run_rows, F, AR_BF16), GGQ_ROW(run_rows, F, AR_F32)}    \
     }
 
 const FormatEntry FORMATS[] = {
@@ -329,6 +321,42 @@ struct Segment {
     uint32_t coarse_shift;
 };
 
+
+// ---- ggq_calibrate: what THIS memory system gives a stream with no arithmetic at all, measured by the product library itself so that bench.py
+// can put the figure in the same JSON line as the dequant kernels' (roofline.measured_*).  Launched like the dequant kernels: one-shot workgroups of
+// 4 waves, each wave instruction covering 1 KiB of contiguous memory (16 B per lane), 8 KiB per workgroup (two rows per wave), no grid-stride loop
+// (a persistent loop is 10-30 % slower on this part for fills: a wave's next store row waits behind vmcnt for the previous one's acknowledgement).
+// KIND: 0 fill, 1 fill with non-temporal stores, 2 copy, 3 copy with non-temporal loads and stores, 4 read-only (the loaded words are folded into
+// one value that is stored only if it equals a constant -- once in 2^32 threads on random data, into the caller's scratch).
+template <int KIND>
+__global__ __launch_bounds__(256) void calibrate_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint64_t n16)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * 512ull + (threadIdx.x >> 6) * 128ull + (threadIdx.x & 63);   // wave w: rows 2w and 2w + 1 of the workgroup's 8
+    uint32_t acc = 0;
+    u32x4 v[2];
+    if constexpr (KIND >= 2) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const uint64_t i = base + 64ull * r;
+            v[r] = u32x4{0u, 0u, 0u, 0u};
+            if (i < n16) v[r] = (KIND == 2) ? in[i] : __builtin_nontemporal_load(in + i);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint64_t i = base + 64ull * r;
+        if (i >= n16) continue;
+        if constexpr (KIND == 0) out[i] = u32x4{(uint32_t)i, 1u, 2u, 3u};
+        else if constexpr (KIND == 1) __builtin_nontemporal_store(u32x4{(uint32_t)i, 1u, 2u, 3u}, out + i);
+        else if constexpr (KIND == 2) out[i] = v[r];
+        else if constexpr (KIND == 3) __builtin_nontemporal_store(v[r], out + i);
+        else acc ^= v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
+    }
+    if constexpr (KIND == 4) {
+        if (acc == 0x9E3779B9u) out[threadIdx.x] = u32x4{acc, acc, acc, acc};
+    }
+}
+
 }  // namespace
 
 #ifdef GGQ_LAB
@@ -357,7 +385,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 9; }
+int ggq_abi_version(void) { return 10; }
 
 #ifndef GGQ_BUILD_ID
 #define GGQ_BUILD_ID "unstamped"
@@ -433,45 +461,28 @@ int ggq_dequant_rows(int qtype, const void* packed, uint64_t n_rows, uint32_t ro
     return e == hipSuccess ? GGQ_OK : hip_fail(e);
 }
 
-int ggq_dequant_batch(const ggq_desc* descs, uint32_t n, void* hip_stream)
+int ggq_calibrate(int kind, const void* src, void* dst, uint64_t bytes, void* hip_stream)
 {
-    if (n > 0 && !descs) return GGQ_ERR_ARG;
-    if (n > GGQ_BATCH_MAX) return GGQ_ERR_ARG;
-    const FormatEntry* fmt[GGQ_BATCH_MAX];
-    for (uint32_t i = 0; i < n; i++) {
-        fmt[i] = find_format(descs[i].qtype);
-        const int rc = check_tensor(fmt[i], descs[i].packed, descs[i].out, descs[i].n_blocks, descs[i].compute_dtype, descs[i].out_dtype);
-        if (rc != GGQ_OK) return rc;                     // nothing has been launched yet
+    if (kind < GGQ_CAL_FILL || kind > GGQ_CAL_READ) return GGQ_ERR_ARG;
+    if (bytes == 0) return GGQ_OK;
+    if (!dst || (kind >= GGQ_CAL_COPY && !src) || (bytes & 15u) != 0 || (kind == GGQ_CAL_READ && bytes < 4096)) return GGQ_ERR_ARG;
+    if (!aligned16(dst) || (src && !aligned16(src))) return GGQ_ERR_ALIGN;
+    const uint64_t n16 = bytes / 16;
+    const uint64_t blocks = (n16 + 511) / 512;
+    if (blocks > MAX_GRID) return GGQ_ERR_ARG;
+    const uint32_t grid = (uint32_t)blocks;
+    const u32x4* in = static_cast<const u32x4*>(src);
+    u32x4* out = static_cast<u32x4*>(dst);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    switch (kind) {
+    case GGQ_CAL_FILL: hipLaunchKernelGGL(calibrate_kernel<0>, dim3(grid), dim3(256), 0, s, in, out, n16); break;
+    case GGQ_CAL_FILL_NT: hipLaunchKernelGGL(calibrate_kernel<1>, dim3(grid), dim3(256), 0, s, in, out, n16); break;
+    case GGQ_CAL_COPY: hipLaunchKernelGGL(calibrate_kernel<2>, dim3(grid), dim3(256), 0, s, in, out, n16); break;
+    case GGQ_CAL_COPY_NT: hipLaunchKernelGGL(calibrate_kernel<3>, dim3(grid), dim3(256), 0, s, in, out, n16); break;
+    default: hipLaunchKernelGGL(calibrate_kernel<4>, dim3(grid), dim3(256), 0, s, in, out, n16); break;
     }
-    bool done[GGQ_BATCH_MAX] = {};
-    for (uint32_t i = 0; i < n; i++) {
-        if (done[i]) continue;
-        // every not-yet-launched tensor of descs[i]'s (format, arithmetic, output dtype), in the caller's order, FEW_MAX per launch
-        Few few;
-        uint32_t k = 0;
-        uint64_t groups = 0;
-        const int cd = descs[i].compute_dtype, od = descs[i].out_dtype;
-        auto flush = [&]() -> hipError_t {
-            const hipError_t e = k ? fmt[i]->few[cd][od](few, k, groups, static_cast<hipStream_t>(hip_stream)) : hipSuccess;
-            k = 0;
-            groups = 0;
-            return e;
-        };
-        for (uint32_t j = i; j < n; j++) {
-            if (done[j] || fmt[j] != fmt[i] || descs[j].compute_dtype != cd || descs[j].out_dtype != od) continue;
-            done[j] = true;
-            if (descs[j].n_blocks == 0) continue;
-            few.d[k++] = Desc{static_cast<const uint8_t*>(descs[j].packed), static_cast<uint8_t*>(descs[j].out), descs[j].n_blocks, groups};
-            groups += (descs[j].n_blocks + fmt[i]->group[cd][od] - 1) / fmt[i]->group[cd][od];
-            if (k == (uint32_t)FEW_MAX) {
-                const hipError_t e = flush();
-                if (e != hipSuccess) return hip_fail(e);
-            }
-        }
-        const hipError_t e = flush();
-        if (e != hipSuccess) return hip_fail(e);
-    }
-    return GGQ_OK;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GGQ_OK : hip_fail(e);
 }
 
 int ggq_plan_create(const ggq_desc* descs, uint32_t n, ggq_plan** plan_out)

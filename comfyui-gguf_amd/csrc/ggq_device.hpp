@@ -584,6 +584,43 @@ GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
     emit_to<F, ARITH, OUT>(f, piece, [&](auto v) { gstore<NT>(out + elem * (uint64_t)OutBytes<OUT>::V, v); });
 }
 
+// fp32 output WITHOUT decoding every chunk twice.  A store instruction must cover 1 KiB of contiguous output, so for 4-byte results a lane
+// can only write a QUAD (16 B) of a chunk per store; the first three rounds therefore had BOTH lanes of a pair decode the same chunk
+// (LDS reads, field extraction, scale products) and keep one half each (Layout<OUT_F32>::PIECES = 2).  Here each lane of a pair decodes
+// its OWN chunk -- the even lane chunk c of the wave's 64, the odd lane chunk c + 32 -- computes both of its quads, and the two swap the
+// halves the other one stores (DPP quad_perm [1,0,3,2]: one v_mov_dpp per dword, or folded into the v_cndmask that selects):
+//     store 1 (first KiB):  even lane <- its own quad 0,  odd lane <- the even lane's quad 1      -> chunk c, contiguous
+//     store 2 (second KiB): even lane <- the odd lane's quad 0,  odd lane <- its own quad 1       -> chunk c + 32
+// With fp16 arithmetic the halves cross as packed fp16 pairs (2 dwords) and are widened afterwards (v_cvt_f32_f16, exact).
+#ifndef GGQ_F32_PAIR_MODE       /* A/B builds: 0 = never (the rounds 1-4 layout), 1 = workgroup teams only, 2 = every team */
+#define GGQ_F32_PAIR_MODE 2
+#endif
+
+GGQ_DEV uint32_t swap_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+
+template <class F, int ARITH>
+GGQ_DEV void pair_f32(const Fields& f, bool odd, f32x4& first, f32x4& second)
+{
+    constexpr int KIND = F::KIND, BIAS = F::BIAS;
+    constexpr bool RB = ARITH == AR_BF16;
+    if constexpr (ARITH == AR_F16) {
+        const u32x2 lo = quad_f16<KIND, BIAS>(f, f.t0), hi = quad_f16<KIND, BIAS>(f, f.t1);
+        const u32x2 give = odd ? lo : hi;
+        const u32x2 got{swap_pair(give.x), swap_pair(give.y)};
+        const u32x2 a = odd ? got : lo, b = odd ? hi : got;
+        const h2 a0 = as_h2(a.x), a1 = as_h2(a.y), b0 = as_h2(b.x), b1 = as_h2(b.y);
+        first = f32x4{(float)a0.x, (float)a0.y, (float)a1.x, (float)a1.y};
+        second = f32x4{(float)b0.x, (float)b0.y, (float)b1.x, (float)b1.y};
+    } else {
+        const u32x4 lo = __builtin_bit_cast(u32x4, rnd4<RB>(quad_f32<KIND, BIAS, RB>(f, f.t0)));
+        const u32x4 hi = __builtin_bit_cast(u32x4, rnd4<RB>(quad_f32<KIND, BIAS, RB>(f, f.t1)));
+        const u32x4 give = odd ? lo : hi;
+        const u32x4 got{swap_pair(give.x), swap_pair(give.y), swap_pair(give.z), swap_pair(give.w)};
+        first = __builtin_bit_cast(f32x4, odd ? got : lo);
+        second = __builtin_bit_cast(f32x4, odd ? hi : got);
+    }
+}
+
 // ============================================================================ the engine
 
 // One tensor (or one contiguous run of blocks) to dequantize.  first_group = number of groups in
@@ -640,12 +677,15 @@ struct Engine {
     static constexpr int CHUNKS = G * CPB;
     static constexpr int PIECES = Layout<OUT>::PIECES;  // lanes per chunk (2 for fp32 output: one quad each)
     static constexpr int NCH = CHUNKS * PIECES / TEAM; // stores per thread per group
+    static constexpr bool PAIRED = OUT == OUT_F32 && (GGQ_F32_PAIR_MODE == 2 || (GGQ_F32_PAIR_MODE == 1 && COOP));   // fp32 output: one decode per chunk, halves swapped inside lane pairs (pair_f32)
+    static constexpr int NIT = CHUNKS / TEAM;           // PAIRED: chunks per thread per group (two stores each)
     static constexpr int SLICE = NU * TEAM * 16;       // LDS bytes per team
     static constexpr int THREADS = WAVES * 64;
     static_assert(GROUP_BYTES % 2 == 0, "block formats are 2-byte aligned");
     static_assert(ALIGNED || (GROUP_BYTES % F::LDS_ALIGN == 0), "group start must keep the format's LDS read alignment");
     static_assert(!SKEW || F::TS % F::LDS_ALIGN == 0, "a row start is a multiple of the block size only");
     static_assert((CHUNKS * PIECES) % TEAM == 0, "a group must be a whole number of 1 KiB store rows per wave");
+    static_assert(!PAIRED || CHUNKS % TEAM == 0, "fp32 output: every wave takes 64 chunks (two 1 KiB store rows) at a time");
 
     GGQ_DEV static void team_sync()
     {
@@ -685,6 +725,32 @@ struct Engine {
         // write-through launches: a Window over this group's slice of the output (base wave-uniform; the per-lane part of the address is 32 bits)
         constexpr uint32_t OB = (uint32_t)OutBytes<OUT>::V;
         [[maybe_unused]] const Window win = window(w.out + b0 * (uint64_t)(BS * OB), (uint32_t)(G * BS) * OB);
+        if constexpr (PAIRED) {
+            const int ll = lane & 63, half = ll >> 1, oddi = ll & 1;
+            const bool odd = oddi != 0;
+            const int wbase = lane - ll;                               // first lane of this wave inside the team
+#pragma unroll
+            for (int s = 0; s < NIT; s++) {
+                const int c0 = TEAM * s + wbase;                       // the wave's 64 chunks of this pass: c0 .. c0 + 63 (2 KiB of fp32)
+                const int chunk = c0 + half + 32 * oddi;               // the one THIS lane decodes
+                const int bl = chunk / CPB, j = chunk % CPB;
+                // (a lane whose own chunk lies past the tensor's end still decodes -- zero-filled LDS -- because its partner needs the swap)
+                const Fields f = F::template fields<true>(slice + a + bl * TS, j);
+                f32x4 v1, v2;
+                pair_f32<F, ARITH>(f, odd, v1, v2);
+                const int c1 = c0 + half, c2 = c1 + 32;                // the chunks this lane STORES a quad of
+                const uint32_t o1 = (uint32_t)c0 * 32u + (uint32_t)ll * 16u, o2 = o1 + 1024u;   // byte offsets inside the group's output
+                if (FULL || b0 + (uint64_t)(c1 / CPB) < w.n_blocks) {
+                    if constexpr (NTS) gstore<true>(w.out + b0 * (uint64_t)(BS * OB) + o1, v1);
+                    else wstore(win, o1, v1);
+                }
+                if (FULL || b0 + (uint64_t)(c2 / CPB) < w.n_blocks) {
+                    if constexpr (NTS) gstore<true>(w.out + b0 * (uint64_t)(BS * OB) + o2, v2);
+                    else wstore(win, o2, v2);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NCH; s++) {
             const int unit = lane + TEAM * s;
@@ -756,25 +822,6 @@ __global__ __launch_bounds__(WAVES * 64) void dequant_many(const Desc* __restric
             }
         }
         const Desc d = table[lo];
-        return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};
-    });
-}
-
-// a FEW tensors of one format, descriptors BY VALUE in the kernel arguments (no device table to build or keep): the next layers' unpacks
-// coalesced into one launch by the host (ggq_dequant_batch: the per-layer call chain of reference ops.py:177 looked a few layers ahead).
-// Finding the tensor of group g is a scan over at most FEW_MAX scalar-loaded first_group values.
-constexpr int FEW_MAX = 8;
-struct Few { Desc d[FEW_MAX]; };
-
-template <class F, int G, int OUT, bool NTL, bool NTS, int WAVES, int ARITH = AR_F16, bool COOP = false>
-__global__ __launch_bounds__(WAVES * 64) void dequant_few(Few few, uint32_t n, uint64_t total_groups, uint32_t xrun_log2)
-{
-    Engine<F, G, OUT, NTL, NTS, WAVES, ARITH, COOP>::run(total_groups, xrun_log2, [&](uint64_t g) {
-        uint32_t lo = 0;
-#pragma unroll
-        for (int i = 1; i < FEW_MAX; i++)
-            if ((uint32_t)i < n && few.d[i].first_group <= g) lo = (uint32_t)i;
-        const Desc d = few.d[lo];
         return Work{(gcptr)d.packed, (gptr)d.out, d.n_blocks, g - d.first_group};
     });
 }

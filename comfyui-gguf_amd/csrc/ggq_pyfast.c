@@ -121,7 +121,7 @@ static struct PyModuleDef fast_module = {PyModuleDef_HEAD_INIT, "_ggq_fast", "fa
 /* ABI: the version of include/ggq.h whose three signatures this file was written against.  _native.fast() refuses a binary whose
  * constant differs from the loaded library's ggq_abi_version(): a stale _ggq_fast would call through raw pointers with the wrong
  * argument lists. */
-#define GGQ_FAST_ABI 9
+#define GGQ_FAST_ABI 10
 
 PyMODINIT_FUNC PyInit__ggq_fast(void)
 {

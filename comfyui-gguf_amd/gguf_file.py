@@ -173,7 +173,9 @@ class GGUFFile:
         order = sorted(tensors, key=lambda t: t.offset)
         runs, where, pos = [], {}, 0                      # runs: (file offset, nbytes, arena offset)
         for t in order:
-            if runs and t.offset <= runs[-1][0] + runs[-1][1] + self.alignment:      # adjacent up to the alignment padding
+            # adjacent up to the alignment padding -- and still 16-byte aligned on the device (what the HIP kernels ask of a tensor's first byte):
+            # files whose general.alignment is 8 or 24 place tensors at 8 (mod 16), those start a run of their own
+            if runs and t.offset <= runs[-1][0] + runs[-1][1] + self.alignment and (t.offset - runs[-1][0]) % 16 == 0:
                 f0, n0, a0 = runs[-1]
                 runs[-1] = (f0, max(n0, t.offset + t.nbytes - f0), a0)
             else:

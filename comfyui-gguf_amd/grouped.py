@@ -92,6 +92,14 @@ class DequantPlan:
             pass
 
 
+def _explicit(device):
+    """torch.device with an explicit index: ``torch.device("cuda") != torch.device("cuda:0")``, and tensors always carry the index."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 class ShardedPlan:
     """One ``DequantPlan`` per shard, shards on several devices (or, for tests on a one-GPU box, several shards on one device).
 
@@ -101,7 +109,7 @@ class ShardedPlan:
     """
 
     def __init__(self, shards, out_dtype=torch.float16, dequant_dtype=None, own_streams=False, indices=None):
-        shards = [(torch.device(d), list(items)) for d, items in shards]
+        shards = [(_explicit(d), list(items)) for d, items in shards]
         if not shards or any(not items for _, items in shards):
             raise ValueError("every shard needs at least one tensor")
         self.devices = [d for d, _ in shards]
@@ -119,7 +127,7 @@ class ShardedPlan:
         """[(device, [indices into entries])] -- ``sharding.partition`` over ``len(devices)`` shards, shard r on ``devices[r]``; shards
         that got nothing (fewer tensors than devices) drop out.  ``entries``: (anything, qtype, shape) triples.  Pure: no GPU needed."""
         from .sharding import partition
-        devices = [torch.device(d) for d in devices]
+        devices = [_explicit(d) for d in devices]
         if not devices:
             raise ValueError("no devices")
         parts = partition([(None, e[1], e[2]) for e in entries], len(devices))
@@ -151,19 +159,22 @@ class ShardedPlan:
                 flat[i] = o
         return flat
 
-    def launch(self):
+    def launch(self, join=True):
         """Enqueue every shard's kernels from the calling thread; returns at once (the host waits for nothing).  With ``own_streams`` every
-        shard runs on its own stream -- ordered after its device's current stream, and that current stream is then made to wait for the shard
-        (a GPU-side dependency): the outputs may be consumed on the current stream as after ``DequantPlan.launch``, while shards that share
-        a device still overlap each other."""
+        shard runs on its own stream -- ordered after its device's current stream, and (``join=True``) that current stream is then made to
+        wait for the shard (a GPU-side dependency): the outputs may be consumed on the current stream as after ``DequantPlan.launch``, while
+        shards that share a device still overlap each other.  The join also means that step k + 1 of EVERY shard of a device waits for step k
+        of all of them; ``join=False`` leaves the shard streams free-running (back-to-back launches of a benchmark; the caller then orders
+        consumers itself: ``synchronize()``, or ``current_stream.wait_stream(plan.streams[k])``) and skips the wait on the current stream."""
         for k, p in enumerate(self.plans):
             if self.streams is None:
                 p.launch()
             else:
-                s, cur = self.streams[k], torch.cuda.current_stream(p.device)
-                s.wait_stream(cur)
+                s = self.streams[k]
+                if join:
+                    s.wait_stream(torch.cuda.current_stream(p.device))
                 p.launch(s)
-        if self.streams is not None:
+        if self.streams is not None and join:
             for s, p in zip(self.streams, self.plans):
                 torch.cuda.current_stream(p.device).wait_stream(s)
         return self.outputs

@@ -35,19 +35,19 @@ callers, token_embd / mmproj tables (reference loader.py:253-254,270,386,397) --
 (dequant.dequantize_tensor_via_gpu) instead of running the reference's torch-CPU ops: same bits, CPU result.  Off by default (it
 touches the GPU at load time, before ComfyUI's model management has placed anything).
 
-``lookahead`` (or ``GGQ_LOOKAHEAD=K``): the unpack of the next K - 1 layers is launched together with the one that was asked for -- one
-kernel launch per K layers instead of K (lookahead.DequantAhead; a dependent kernel boundary costs ~1.3 us on MI355X and a single-layer
-launch cannot overlap its reads with its writes).  Same kernels, same bits, fresh tensors; opt-in because up to K - 1 dense weights are
-alive ahead of their use (VRAM the reference's estimate does not see).
-
 ``fast`` (or ``GGQ_FAST=1``): ``fused_small_m`` + ``fused_mfma`` + ``gather_embedding`` in one switch -- the opt-ins that hold no VRAM and measured faster
 wherever they apply.
 
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
 overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
-and unpacked on a side stream while the current layer's GEMM runs (``overlap="all"``: also for weights already in HBM, where it
-measured slower).  Bit-identical values; opt-in because the dense weight handed out is a view into a scratch buffer that is
+and unpacked on a side stream while the current layer's GEMM runs (weights already in HBM are left alone: prefetching those measured slower in
+every run on record, EXPERIMENTS.md Part R4).  Bit-identical values; opt-in because the dense weight handed out is a view into a scratch buffer that is
 reused two layers later (see overlap.py).
+
+VRAM accounting: whenever an option that HOLDS device memory is on (``dense_cache_gb``, ``overlap``), ``install()`` also wraps
+``GGMLLayer.ggml_save_to_state_dict`` (reference ops.py:145-160) -- the fake state dict ComfyUI's model management sizes a GGUF model
+by -- so that the layer marked ``largest_layer`` reports one more meta tensor, ``temp.ggq_scratch``, of the options' worst case
+(``scratch_reservation``): nobody has to edit the reference for ComfyUI to know.  A default install adds nothing.
 """
 import os
 
@@ -57,19 +57,41 @@ from . import dequant as _hip
 
 _installed = {}
 
+# The default of install() / the drop-in when neither ``fast`` / ``exact`` nor one of the three options' own switches says otherwise.
+# True since round 5: the fused kernels use the SAME weights bit for bit and differ from ``F.linear`` only in the order of an fp32
+# summation that is hipBLASLt's implementation detail, not a contract of the reference (ops.py:242-244 calls F.linear and takes what
+# the BLAS library does).  Measured against an fp64 evaluation on the oracle's weights on every FLUX.1-dev / SD3.5-large / T5-xxl linear
+# shape, 1 / 4 / 64 / 256 rows, bf16 and fp16 (tools/fused_error.py -> profiles/r05_fused_error.json): the fused results are no further
+# from the exact product than F.linear's (RMS within 2 %, max within one output rounding step) and reproduce run to run; the default
+# install otherwise costs 20-48 % of a FLUX step at <= 1024 tokens.  ``exact=True`` / ``GGQ_EXACT=1`` keeps
+# every linear on unpack + F.linear (bit-equal to the reference's own output on the same GPU).
+DEFAULT_FAST = True
+
+
+def _env_flag(name):
+    return os.environ.get(name, "0") not in ("", "0")
+
 
 def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
-            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, lookahead=None, fast=None):
+            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, fast=None, exact=None):
     """Patch the reference modules in place; returns the dict of original functions.
 
-    ``fast`` (or ``GGQ_FAST=1``; needs ``ref_ops``): the three opt-ins that hold no VRAM and measured faster wherever they apply, in one switch --
-    ``fused_small_m`` + ``fused_mfma`` (same weights, results equal to F.linear up to fp32 summation order) + ``gather_embedding`` (bit-identical).
-    An option given explicitly (argument or its own environment variable) wins over the switch."""
+    ``fast`` (or ``GGQ_FAST=1``; needs ``ref_ops``): ``fused_small_m`` + ``fused_mfma`` (same weights, results as close to the exact product as
+    F.linear's, in another fp32 summation order) + ``gather_embedding`` (bit-identical) -- the options that hold no VRAM and measured faster
+    wherever they apply.  It is the DEFAULT when ``ref_ops`` is given (``DEFAULT_FAST``); ``exact=True`` (or ``GGQ_EXACT=1``) turns it off: every
+    linear then runs unpack + F.linear, bit-equal to the reference on the same GPU.  An option given explicitly (argument or its own
+    environment variable) wins over both switches."""
     if id(ref_dequant) in _installed:
         return _installed[id(ref_dequant)]["orig"]
-    if fast is None:
-        fast = os.environ.get("GGQ_FAST", "0") not in ("", "0")
-    if fast and ref_ops is not None:
+    if exact is None:
+        exact = _env_flag("GGQ_EXACT")
+    asked_fast = fast if fast is not None else (_env_flag("GGQ_FAST") if "GGQ_FAST" in os.environ else None)
+    if asked_fast and exact:
+        raise ValueError("fast and exact (GGQ_FAST / GGQ_EXACT) contradict each other")
+    if asked_fast and ref_ops is None:
+        raise ValueError("fast patches GGMLOps.Linear / GGMLOps.Embedding: pass ref_ops")
+    fast = bool(asked_fast) if asked_fast is not None else (DEFAULT_FAST and not exact and ref_ops is not None)
+    if fast:
         fused_small_m = True if fused_small_m is None and "GGQ_FUSED_SMALL_M" not in os.environ else fused_small_m
         fused_mfma = True if fused_mfma is None and "GGQ_FUSED_MFMA" not in os.environ else fused_mfma
         gather_embedding = True if gather_embedding is None and "GGQ_GATHER_EMBEDDING" not in os.environ else gather_embedding
@@ -80,13 +102,6 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
     hip_dequantize, hip_dequantize_tensor = _hip.dequantize, _hip.dequantize_tensor
     if dense_cache_gb is None and os.environ.get("GGQ_DENSE_CACHE_GB"):
         dense_cache_gb = float(os.environ["GGQ_DENSE_CACHE_GB"])
-    if lookahead is None and os.environ.get("GGQ_LOOKAHEAD"):
-        lookahead = int(os.environ["GGQ_LOOKAHEAD"])
-    ahead = None
-    if lookahead and int(lookahead) > 1:
-        from .lookahead import DequantAhead
-        ahead = DequantAhead(int(lookahead), hip_dequantize_tensor)
-        hip_dequantize_tensor = ahead               # GGQUnsupported from the wrapped function passes straight through
     cache = None
     if dense_cache_gb:
         from .resident import DenseCache
@@ -130,38 +145,38 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
             mod.dequantize_tensor = dequantize_tensor
             patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
     if fused_small_m is None:
-        fused_small_m = os.environ.get("GGQ_FUSED_SMALL_M", "0") not in ("", "0")
+        fused_small_m = _env_flag("GGQ_FUSED_SMALL_M")
     if fused_mfma is None:
-        fused_mfma = os.environ.get("GGQ_FUSED_MFMA", "0") not in ("", "0")
+        fused_mfma = _env_flag("GGQ_FUSED_MFMA")
     if fused_mfma_max_m is None:
         fused_mfma_max_m = int(os.environ.get("GGQ_FUSED_MFMA_MAX_M", "256"))
     if fused_small_m or fused_mfma:
         if ref_ops is None:
             raise ValueError("fused_small_m / fused_mfma patch GGMLOps.Linear: pass ref_ops")
         patched.append(_fuse_linear(ref_ops.GGMLOps.Linear, unsupported, bool(fused_small_m), fused_mfma_max_m if fused_mfma else 0))
-    elif ref_ops is not None and hasattr(getattr(ref_ops, "GGMLOps", None), "Linear"):
-        patched.append(_recommend_small_m(ref_ops.GGMLOps.Linear))
     if gather_embedding is None:
-        gather_embedding = os.environ.get("GGQ_GATHER_EMBEDDING", "0") not in ("", "0")
+        gather_embedding = _env_flag("GGQ_GATHER_EMBEDDING")
     if gather_embedding:
         if ref_ops is None:
             raise ValueError("gather_embedding patches GGMLOps.Embedding: pass ref_ops")
         patched.append(_gather_embedding(ref_ops.GGMLOps.Embedding, unsupported))
     if overlap is None:
-        overlap = os.environ.get("GGQ_OVERLAP", "0")
-        overlap = "all" if overlap == "all" else overlap not in ("", "0")
+        overlap = _env_flag("GGQ_OVERLAP")
     prefetcher = None
     if overlap:
         if ref_ops is None:
             raise ValueError("overlap patches GGMLLayer.cast_bias_weight: pass ref_ops")
         from .overlap import attach
-        record, prefetcher = attach(ref_ops.GGMLLayer, resident=(overlap == "all"))
+        record, prefetcher = attach(ref_ops.GGMLLayer)
         patched.append(record)
     options = {"dense_cache_gb": dense_cache_gb or None, "fused_small_m": bool(fused_small_m) or None, "fused_mfma": (fused_mfma_max_m if fused_mfma else None),
-               "gather_embedding": bool(gather_embedding) or None, "overlap": overlap or None, "cpu_route_mb": cpu_route_mb or None,
-               "lookahead": lookahead if ahead is not None else None}
-    _installed[id(ref_dequant)] = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher, "ahead": ahead,
-                                   "options": {k: v for k, v in options.items() if v is not None}}
+               "gather_embedding": bool(gather_embedding) or None, "overlap": bool(overlap) or None, "cpu_route_mb": cpu_route_mb or None,
+               "exact": bool(exact) or None}
+    rec = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher,
+           "options": {k: v for k, v in options.items() if v is not None}}
+    if (dense_cache_gb or overlap) and ref_ops is not None and hasattr(getattr(ref_ops, "GGMLLayer", None), "ggml_save_to_state_dict"):
+        patched.append(_account_scratch(ref_ops.GGMLLayer, rec))
+    _installed[id(ref_dequant)] = rec
     return orig
 
 
@@ -169,58 +184,67 @@ def describe(ref_dequant):
     """'; options: ...' of an installation, for the one log line the drop-in prints (autoinstall.py)."""
     rec = _installed.get(id(ref_dequant)) or {}
     names = sorted({f"{getattr(o, '__name__', o)}.{n}" for o, n, _ in rec.get("patched", [])} - {"dequantize", "dequantize_tensor"})
-    opts = ", ".join(f"{k}={v}" for k, v in rec.get("options", {}).items()) or "defaults: bit-exact unpack + F.linear"
+    opts = ", ".join(f"{k}={v}" for k, v in rec.get("options", {}).items()) or "bit-exact unpack + F.linear"
+    if rec.get("options", {}).get("fused_small_m") or rec.get("options", {}).get("fused_mfma"):
+        opts += " (fused linears: same weights bit for bit, fp32 summation in the kernel's order; GGQ_EXACT=1 keeps unpack + F.linear everywhere)"
     return f"; patched {', '.join(names)}; {opts}"
 
 
-_SMALL_M_HINT = ("comfyui-gguf_amd: this model runs quantized linears on inputs of <= 4 rows (modulation layers): each call unpacks the whole weight for a "
-                 "GEMV (about 3 ms per FLUX.1-dev step).  GGQ_FUSED_SMALL_M=1 (install(fused_small_m=True)) fuses them -- results equal to F.linear "
-                 "up to fp32 summation order instead of bit for bit, which is why it is not the default.  GGQ_FAST=1 turns on every such option at once.")
-
-
-def _recommend_small_m(linear_cls, probe_calls=4096):
-    """Default installs only: a pass-through wrapper of ``linear_cls.forward_ggml_cast_weights`` that logs ``_SMALL_M_HINT`` ONCE, the
-    first time a quantized weight of >= 1 M elements meets an input of <= 4 rows, and then takes itself out again (also after
-    ``probe_calls`` calls without such a layer): zero cost from then on.  Returns the record uninstall() restores."""
-    import logging
-    reference_forward = linear_cls.forward_ggml_cast_weights
-    left = [probe_calls]
-
-    def forward_ggml_cast_weights(self, input):
-        if _hip._is_compiling():                                 # torch.compile traces the reference's method only
-            return reference_forward(self, input)
-        left[0] -= 1
-        cols = input.shape[-1]
-        hit = cols and input.numel() // cols <= 4 and hasattr(self.weight, "tensor_type") and self.weight.numel() >= (1 << 20) and input.is_cuda
-        if hit:
-            logging.getLogger("comfyui-gguf_amd").warning(_SMALL_M_HINT)
-        if (hit or left[0] <= 0) and linear_cls.forward_ggml_cast_weights is forward_ggml_cast_weights:
-            linear_cls.forward_ggml_cast_weights = reference_forward
-        return reference_forward(self, input)
-
-    forward_ggml_cast_weights.__wrapped__ = reference_forward
-    linear_cls.forward_ggml_cast_weights = forward_ggml_cast_weights
-    return (linear_cls, "forward_ggml_cast_weights", reference_forward)
-
-
 def scratch_bytes(ref_dequant):
-    """Device memory the opt-ins of this installation hold that the reference's VRAM estimate knows nothing about: the resident dense
-    weights (dense_cache_gb), the side-stream scratch and staging slots (overlap) and the dense weights unpacked ahead of their use
-    (lookahead), in bytes, by option.  INTEGRATION.md section 5 shows where a maintainer adds the total to the ``temp.weight`` reservation
-    of ``ggml_save_to_state_dict`` (reference ops.py:153-158), which is how ComfyUI's model management learns how much VRAM a loaded
-    GGUF model needs beyond its packed bytes."""
+    """Device memory the opt-ins of this installation hold RIGHT NOW that the reference's VRAM estimate knows nothing about: the resident
+    dense weights (dense_cache_gb) and the side-stream scratch and staging slots (overlap), in bytes, by option.  What ComfyUI is TOLD is
+    the worst case, ``scratch_reservation``, through the wrapped ``ggml_save_to_state_dict`` (``_account_scratch``)."""
     rec = _installed.get(id(ref_dequant)) or {}
     out = {"dense_cache": rec["cache"].scratch_bytes() if rec.get("cache") is not None else 0,
-           "overlap": rec["prefetcher"].scratch_bytes() if rec.get("prefetcher") is not None else 0,
-           "lookahead": rec["ahead"].scratch_bytes() if rec.get("ahead") is not None else 0}
+           "overlap": rec["prefetcher"].scratch_bytes() if rec.get("prefetcher") is not None else 0}
     out["total"] = sum(out.values())
     return out
 
 
-def lookahead_stats(ref_dequant):
-    """``DequantAhead.stats()`` of an installation (None when ``lookahead`` is off)."""
-    rec = _installed.get(id(ref_dequant))
-    return rec["ahead"].stats() if rec and rec.get("ahead") is not None else None
+OVERLAP_DENSE_SLOTS, OVERLAP_PACKED_SLOTS = 2, 3      # overlap.LayerPrefetcher: dense scratch slots and packed staging slots per device
+
+
+def scratch_reservation(ref_dequant_or_rec, largest_dense_bytes, largest_packed_bytes):
+    """WORST-CASE bytes the memory-holding options of an installation can come to hold, by option: ``dense_cache_gb`` its whole budget;
+    ``overlap`` 2 dense scratch slots + 3 packed staging slots, each grown to the largest layer.  The fused kernels, ``gather_embedding``
+    and ``cpu_route_mb`` hold nothing beyond their call; a default install reserves 0."""
+    rec = ref_dequant_or_rec if isinstance(ref_dequant_or_rec, dict) else (_installed.get(id(ref_dequant_or_rec)) or {})
+    opts = rec.get("options", {})
+    out = {"dense_cache": int(opts["dense_cache_gb"] * 1e9) if opts.get("dense_cache_gb") else 0,
+           "overlap": OVERLAP_DENSE_SLOTS * int(largest_dense_bytes) + OVERLAP_PACKED_SLOTS * int(largest_packed_bytes) if opts.get("overlap") else 0}
+    out["total"] = sum(out.values())
+    return out
+
+
+def _account_scratch(layer_cls, rec):
+    """Wrap ``layer_cls.ggml_save_to_state_dict`` (reference ops.py:145-160): the fake state dict ComfyUI's model management sizes a GGUF
+    model by.  The reference reports, for the layer marked ``largest_layer`` (loader.py:134-137), one ``temp.weight`` of the dense size --
+    "space required for dequantizing the largest tensor" (ops.py:153-158); that is exactly what the default path needs.  Options that hold
+    more add ONE more meta tensor in that same branch, ``temp.ggq_scratch``, uint8 of ``scratch_reservation(...)["total"]`` bytes, so that
+    ComfyUI keeps that much VRAM free when it decides what to load ("a replacement that needs scratch beyond
+    numel x 2 must account for it here").  Returns the (owner, name, original) record uninstall() restores."""
+    reference_save = layer_cls.ggml_save_to_state_dict
+
+    def ggml_save_to_state_dict(self, destination, prefix, keep_vars):
+        out = reference_save(self, destination, prefix, keep_vars)
+        if getattr(self, "largest_layer", False):
+            weight = self.weight
+            shape = getattr(weight, "tensor_shape", weight.shape)
+            temp = destination.get(prefix + "temp.weight")
+            elem = temp.element_size() if temp is not None else 2        # the dtype rule of ops.py:156
+            dense = elem
+            for d in shape:
+                dense *= int(d)
+            with torch._C.DisableTorchFunctionSubclass():
+                packed = weight.numel() * weight.element_size()           # the bytes as stored (GGMLTensor.shape is the LOGICAL shape)
+            extra = scratch_reservation(rec, dense, packed)["total"]
+            if extra:
+                destination[prefix + "temp.ggq_scratch"] = torch.empty(extra, device=torch.device("meta"), dtype=torch.uint8)
+        return out
+
+    ggml_save_to_state_dict.__wrapped__ = reference_save
+    layer_cls.ggml_save_to_state_dict = ggml_save_to_state_dict
+    return (layer_cls, "ggml_save_to_state_dict", reference_save)
 
 
 def _gather_embedding(embedding_cls, unsupported):
@@ -294,5 +318,3 @@ def uninstall(ref_dequant):
             rec["cache"].clear()
         if rec.get("prefetcher") is not None:
             rec["prefetcher"].close()
-        if rec.get("ahead") is not None:
-            rec["ahead"].clear()

@@ -148,46 +148,48 @@ def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=Fal
     if devices is not None:
         if device is not None or shard is not None:
             raise ValueError("devices=[...] places the shards itself: do not pass device= or shard=")
-        devices = list(devices)
+        devices = [torch.device(d) for d in devices]
         if not devices:
             raise ValueError("devices=[...] is empty")
-        merged, arch = {}, None
-        for r, dev in enumerate(devices):
-            part, arch = gguf_sd_loader(path, handle_prefix, True, is_text_model, device=dev, detect_arch=detect_arch,
-                                        upload_threads=upload_threads, shard=(r, len(devices)))
-            for v in part.values():
-                if getattr(v, "is_largest_weight", False):
-                    del v.is_largest_weight                   # per-shard marks: re-marked over the whole dict below
-            merged.update(part)
-        quantized = [key for key, value in merged.items() if is_quantized(value)]
-        if quantized:
-            merged[max(quantized, key=lambda key: merged[key].numel())].is_largest_weight = True
-        return (merged, arch) if return_arch else merged
-    with GGUFFile(path) as reader:
+    with GGUFFile(path) as reader:                      # ONE parse, whatever the placement (round 4 re-opened the file once per device)
         selected = _select(reader, handle_prefix)
         arch, compat = _architecture(reader, path, [key for key, _ in selected], is_text_model, detect_arch)
         if compat:
             logging.warning(f"Warning: This gguf model file is loaded in compatibility mode '{compat}' [arch:{arch}]")
 
-        where = None
-        if shard is not None:
-            if device is None:
+        # where every selected tensor's bytes live: {tensor name: (arena, byte offset)}; None = the reference's CPU mmap views
+        placed = None
+        if shard is not None or devices is not None:
+            if shard is not None and device is None:
                 raise ValueError("shard=(rank, world_size) selects what is uploaded: it needs device=")
             from .sharding import partition
-            rank, world = shard
+            rank, world = shard if shard is not None else (None, len(devices))
             manifest = [(key, t.tensor_type, tuple(int(d) for d in reversed(t.shape)) or (1,)) for key, t in selected]
             costed = [m if m[1] in _BYTES_KNOWN else (m[0], Q.F16, m[2]) for m in manifest]       # unknown types: cost as 2 B/element
-            mine = partition(costed, world)[rank]
-            selected = [selected[i] for i in mine]
-            arena, where = reader.upload_tensors(device, [t for _, t in selected], threads=upload_threads)
-        else:
-            arena = None if device is None else reader.upload(device, threads=upload_threads)
-        state_dict, counts = {}, {}
-        for key, tensor in selected:
-            if where is not None:
-                raw = arena[where[tensor.name]: where[tensor.name] + tensor.nbytes]
+            parts = partition(costed, world)                                                       # computed ONCE; every rank / device agrees
+            placed = {}
+            for r, dev in ([(rank, device)] if shard is not None else list(enumerate(devices))):
+                mine = [selected[i][1] for i in parts[r]]
+                if mine:
+                    arena, where = reader.upload_tensors(dev, mine, threads=upload_threads)
+                    placed.update({name: (arena, off) for name, off in where.items()})
+            if shard is not None:
+                selected = [selected[i] for i in parts[rank]]                                      # a rank returns its share only, in file order
+        elif device is not None:
+            if reader.alignment % 16:
+                # general.alignment 8 / 24 / ...: offsets in the file are not all 16-byte aligned -- re-pack so that every tensor is
+                arena, where = reader.upload_tensors(device, [t for _, t in selected], threads=upload_threads)
+                placed = {name: (arena, off) for name, off in where.items()}
             else:
-                raw = tensor.data if arena is None else reader.device_bytes(arena, tensor)
+                arena = reader.upload(device, threads=upload_threads)
+                placed = {t.name: (arena, t.offset) for _, t in selected}
+        state_dict, counts = {}, {}
+        for key, tensor in selected:                   # the file's order (the reference loader's), also when the tensors span devices
+            if placed is not None:
+                arena, off = placed[tensor.name]
+                raw = arena[off: off + tensor.nbytes]
+            else:
+                raw = tensor.data
             shape = _logical_shape(reader, tensor, arch, compat)
             plain = _PLAIN_DTYPES.get(tensor.tensor_type)
             if plain is not None:
@@ -208,22 +210,34 @@ def gguf_sd_loader(path, handle_prefix="model.diffusion_model.", return_arch=Fal
     return (state_dict, arch) if return_arch else state_dict
 
 
-def state_dict_plan(state_dict, dtype=torch.float16, dequant_dtype=None):
-    """One ``DequantPlan`` over every GPU-resident quantized tensor of a state dict that has a HIP
-    unpacker: the whole weight set dequantized by one launch per (format, mode).  Returns
-    (plan, keys) with ``plan.outputs[i]`` the dense tensor of ``keys[i]``."""
+def _plan_items(state_dict):
     from .dequant import hip_supported
-    from .grouped import DequantPlan
     keys = [k for k, v in state_dict.items() if is_quantized(v) and hip_supported(v.tensor_type) and v.is_cuda]
     if not keys:
         raise ValueError("no GPU-resident quantized tensors with a HIP unpacker in this state dict")
-    items = [(state_dict[k].as_subclass(torch.Tensor), state_dict[k].tensor_type, tuple(state_dict[k].tensor_shape)) for k in keys]
-    on = {}
-    for k, it in zip(keys, items):
-        on.setdefault(it[0].device, []).append((k, it))
-    if len(on) > 1:
-        # loaded with devices=[...]: one plan per device, keys regrouped device by device (plan.outputs[s][i] <-> keys[s][i])
-        from .grouped import ShardedPlan
-        return (ShardedPlan([(d, [it for _, it in rows]) for d, rows in on.items()], out_dtype=dtype, dequant_dtype=dequant_dtype),
-                [[k for k, _ in rows] for rows in on.values()])
+    return keys, [(state_dict[k].as_subclass(torch.Tensor), state_dict[k].tensor_type, tuple(state_dict[k].tensor_shape)) for k in keys]
+
+
+def state_dict_plan(state_dict, dtype=torch.float16, dequant_dtype=None):
+    """One ``DequantPlan`` over every GPU-resident quantized tensor of a state dict that has a HIP
+    unpacker: the whole weight set dequantized by one launch per (format, mode).  Returns
+    (plan, keys) with ``plan.outputs[i]`` the dense tensor of ``keys[i]``.  A state dict loaded with ``devices=[...]`` spans several
+    GPUs: that is ``state_dict_sharded_plan`` (another return shape -- asking for it here raises instead of silently changing this one's)."""
+    from .grouped import DequantPlan
+    keys, items = _plan_items(state_dict)
+    if len({it[0].device for it in items}) > 1:
+        raise ValueError("this state dict spans several devices (gguf_sd_loader(devices=[...])): use state_dict_sharded_plan()")
     return DequantPlan(items, out_dtype=dtype, dequant_dtype=dequant_dtype), keys
+
+
+def state_dict_sharded_plan(state_dict, dtype=torch.float16, dequant_dtype=None):
+    """The same for a state dict whose tensors live on SEVERAL GPUs (``gguf_sd_loader(devices=[...])``): one ``grouped.ShardedPlan`` -- a
+    ``DequantPlan`` per device, every launch enqueued by the calling thread.  Returns (plan, keys): ``keys`` in the state dict's order and
+    ``plan.outputs_in_order()[i]`` the dense tensor of ``keys[i]`` (on that tensor's own device)."""
+    from .grouped import ShardedPlan
+    keys, items = _plan_items(state_dict)
+    on = {}
+    for i, it in enumerate(items):
+        on.setdefault(it[0].device, []).append(i)
+    shards = [(d, [items[i] for i in ix]) for d, ix in on.items()]
+    return ShardedPlan(shards, out_dtype=dtype, dequant_dtype=dequant_dtype, indices=list(on.values())), keys

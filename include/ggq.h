@@ -75,6 +75,14 @@ int ggq_abi_version(void);
  * measured on. */
 const char* ggq_build_id(void);
 
+/* Memory-system probes with no arithmetic: the MEASURED ceiling bench.py prints beside the spec peak (roofline.measured_fill_GBps / _copy_GBps /
+ * _read_GBps, and the read/write-weighted blend of them for each kernel's own traffic mix).  One kernel per call over `bytes` bytes (a multiple of
+ * 16), 16 B per lane, every wave instruction covering 1 KiB of contiguous memory like the dequant kernels' accesses: FILL writes dst; COPY reads src
+ * and writes dst; READ reads src only (dst = at least 4 KiB of scratch that is practically never written); the _NT kinds use non-temporal accesses.
+ * Replaces: nothing in the reference -- measurement only ("6.29 TB/s measured copy ceiling" is this figure, per box). */
+typedef enum ggq_cal_kind { GGQ_CAL_FILL = 0, GGQ_CAL_FILL_NT = 1, GGQ_CAL_COPY = 2, GGQ_CAL_COPY_NT = 3, GGQ_CAL_READ = 4 } ggq_cal_kind;
+int ggq_calibrate(int kind, const void* src, void* dst, uint64_t bytes, void* hip_stream);
+
 /* ---- one tensor ---------------------------------------------------------------------------- */
 
 /* Dequantize n_blocks consecutive blocks: packed[n_blocks * type_size] -> out[n_blocks * block_size].
@@ -119,15 +127,6 @@ typedef struct ggq_desc {
     int32_t compute_dtype;  /* ggq_dtype the arithmetic runs in (GGQ_F16 = stock path) */
     int32_t reserved;       /* must be 0 */
 } ggq_desc;
-
-/* A FEW tensors, one call, nothing to build or keep: `descs` is HOST memory, read before the call returns; tensors of one
- * (qtype, compute_dtype, out_dtype) go into ONE kernel launch (their descriptors travel by value in the kernel arguments, up to 8
- * per launch), in the caller's order.  Same kernels and values as n ggq_dequant calls, minus n - 1 kernel boundaries.
- * Replaces: the NEXT FEW dequantize_tensor() calls of the per-layer chain (ops.py:177) -- lookahead.py runs the unpack of the
- * layers it expects next together with the one that was asked for.  n <= GGQ_BATCH_MAX; arguments are checked for every entry
- * before anything is launched. */
-#define GGQ_BATCH_MAX 32
-int ggq_dequant_batch(const ggq_desc* descs, uint32_t n, void* hip_stream);
 
 typedef struct ggq_plan ggq_plan;
 

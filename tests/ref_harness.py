@@ -93,9 +93,13 @@ def lora_patch(shape, seed, strength=0.5):
 
 
 class Installed:
-    """``with Installed(pkg, mods, **options):`` -- install() over the reference modules for the duration of the block."""
+    """``with Installed(pkg, mods, **options):`` -- install() over the reference modules for the duration of the block.  ``exact=True`` unless the
+    test says ``fast`` / ``exact`` itself: these tests compare with the reference's own output BIT FOR BIT, which is what ``exact`` promises (the
+    round-5 default additionally fuses small linears: tolerance parity, tested where it is asked for by name)."""
 
     def __init__(self, pkg, mods, **options):
+        if "fast" not in options:
+            options.setdefault("exact", True)
         self.pkg, self.mods, self.options = pkg, mods, options
 
     def __enter__(self):

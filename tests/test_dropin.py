@@ -74,13 +74,14 @@ def test_reference_first_then_this_package(custom_nodes, caplog):
         amd_mod = _comfy_load_custom_node(amd_dir)
     _assert_installed(ref_mod, amd_mod)
     assert sum("HIP dequant path installed over" in r.getMessage() for r in caplog.records) == 1      # one line, saying what was patched
-    assert "dequantize_tensor" in caplog.text and "defaults" in caplog.text
+    # the default since round 5: the no-VRAM opt-ins are ON (install.DEFAULT_FAST), and the one log line says so and names the way back
+    assert "dequantize_tensor" in caplog.text and "fused_small_m=True" in caplog.text and "fused_mfma=256" in caplog.text and "GGQ_EXACT=1" in caplog.text
 
 
 def test_this_package_first_then_reference(custom_nodes):
     ref_dir, amd_dir = custom_nodes
     amd_mod = _comfy_load_custom_node(amd_dir)
-    assert amd_mod.autoinstall._state == {"armed": True, "installed": None}
+    assert amd_mod.autoinstall._state == {"armed": True, "installed": None, "gave_up": False}
     assert any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)
     import json                                                   # unrelated imports pass through the armed hook untouched
     assert json.loads("1") == 1
@@ -98,32 +99,59 @@ def test_not_armed_outside_comfyui(custom_nodes, monkeypatch):
     assert not hasattr(sys.modules[ref_mod.__name__ + ".dequant"].dequantize_tensor, "__wrapped__")
 
 
-def test_small_m_recommendation_is_logged_once_and_removes_itself(custom_nodes, caplog):
-    """Default installs watch GGMLOps.Linear for one-to-four-row inputs on big quantized weights, say ONCE that GGQ_FUSED_SMALL_M=1
-    would fuse them, and take the watcher out again."""
+def test_ggq_exact_restores_the_bit_exact_default(custom_nodes, monkeypatch, caplog):
+    """GGQ_EXACT=1: nothing above dequantize / dequantize_tensor is patched -- every linear runs unpack + F.linear, as in rounds 1-4."""
     ref_dir, amd_dir = custom_nodes
+    monkeypatch.setenv("GGQ_EXACT", "1")
     ref_mod = _comfy_load_custom_node(ref_dir)
+    with caplog.at_level(logging.INFO, logger="comfyui-gguf_amd"):
+        amd_mod = _comfy_load_custom_node(amd_dir)
+    ro, rd = sys.modules[ref_mod.__name__ + ".ops"], sys.modules[ref_mod.__name__ + ".dequant"]
+    assert hasattr(rd.dequantize_tensor, "__wrapped__")
+    assert not hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__")
+    assert not hasattr(ro.GGMLOps.Embedding.forward_ggml_cast_weights, "__wrapped__")
+    assert not hasattr(ro.GGMLLayer.ggml_save_to_state_dict, "__wrapped__")
+    assert "exact=True" in caplog.text and "fused_small_m" not in caplog.text
+    amd_mod.install.uninstall(rd)
+
+
+def test_unrelated_ops_modules_pass_through_the_armed_hook(custom_nodes, tmp_path, monkeypatch):
+    """``torchvision.ops``, ``comfy.ops`` ... -- any ``*.ops`` whose package has no ``dequant`` sibling -- must not be re-resolved
+    through the other finders nor get its loader touched while the hook waits for ComfyUI-GGUF."""
+    ref_dir, amd_dir = custom_nodes
     amd_mod = _comfy_load_custom_node(amd_dir)
-    ro = sys.modules[ref_mod.__name__ + ".ops"]
-    Linear = ro.GGMLOps.Linear
-    watcher = Linear.forward_ggml_cast_weights
-    assert hasattr(watcher, "__wrapped__")
-    Q = amd_mod.qtypes.Q
-    w = ro.GGMLTensor(torch.from_numpy(amd_mod.synth.make_tensor_bytes(Q.Q8_0, (1024, 1024), seed=5).copy()), tensor_type=Q.Q8_0, tensor_shape=torch.Size((1024, 1024)))
-    lin = Linear(1024, 1024)
-    lin.weight, lin.bias = torch.nn.Parameter(w, requires_grad=False), None
+    other = tmp_path / "otherpkg"
+    other.mkdir()
+    (other / "__init__.py").write_text("")
+    (other / "ops.py").write_text("GGMLOps = GGMLTensor = GGMLLayer = object\n")        # even with the right names: no dequant.py next to it
+    monkeypatch.syspath_prepend(str(tmp_path))
+    import otherpkg.ops
+    assert type(otherpkg.ops.__spec__.loader).__name__ != "_HookedLoader"
+    assert amd_mod.autoinstall._state["installed"] is None and any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)
+    ref_mod = _comfy_load_custom_node(ref_dir)                     # the real one still gets picked up afterwards
+    _assert_installed(ref_mod, amd_mod)
 
-    class OnGpu(torch.Tensor):                                     # a CPU tensor that says it is a GPU one: the watcher only looks, the reference computes
-        is_cuda = True
 
-    x = torch.randn(1, 1024)
-    with caplog.at_level(logging.WARNING, logger="comfyui-gguf_amd"):
-        y = lin(x.as_subclass(OnGpu))
-        assert Linear.forward_ggml_cast_weights is watcher.__wrapped__           # took itself out after the hit
-        lin(x.as_subclass(OnGpu))
-    assert sum("GGQ_FUSED_SMALL_M=1" in r.getMessage() for r in caplog.records) == 1
-    assert torch.equal(torch.Tensor(y), lin(x))
-    amd_mod.install.uninstall(sys.modules[ref_mod.__name__ + ".dequant"])
+def test_a_failing_install_is_logged_once_and_the_hook_gives_up(custom_nodes, monkeypatch, caplog):
+    """install() raising must not leave the finder at sys.meta_path[0] retrying (and logging) on every later ``*.ops`` import."""
+    ref_dir, amd_dir = custom_nodes
+    amd_mod = _comfy_load_custom_node(amd_dir)
+    calls = []
+
+    def boom(*a, **k):
+        calls.append(1)
+        raise RuntimeError("no such device")
+    monkeypatch.setattr(amd_mod.install, "install", boom)
+    with caplog.at_level(logging.ERROR, logger="comfyui-gguf_amd"):
+        ref_mod = _comfy_load_custom_node(ref_dir)
+    rd = sys.modules[ref_mod.__name__ + ".dequant"]
+    assert calls == [1] and amd_mod.autoinstall._state["gave_up"] and amd_mod.autoinstall._state["installed"] is None
+    assert not hasattr(rd.dequantize_tensor, "__wrapped__")                                  # the reference keeps its own torch path
+    assert not any(type(f).__name__ == "_AfterOpsImport" for f in sys.meta_path)             # gone, not waiting for the next *.ops
+    assert sum("could not install over" in r.getMessage() for r in caplog.records) == 1
+    amd_mod.autoinstall._install_over(sys.modules[ref_mod.__name__ + ".ops"])               # a later attempt is a no-op: no second traceback
+    assert calls == [1]
+    amd_mod.autoinstall._state.update(armed=False, installed=None, gave_up=False)
 
 
 def test_ggq_fast_switch_turns_on_the_no_vram_opt_ins(custom_nodes, monkeypatch, caplog):

@@ -138,7 +138,7 @@ def test_rccl_failure_falls_back_to_gloo_fences_and_says_so():
     """GGQ_BENCH_BACKEND=try-nccl: the rig WITH the RCCL attempt.  Two ranks on this box's one GPU: RCCL refuses (duplicate device), every rank learns
     so over the gloo control group, the fences fall back to gloo and the line says why in world.backend -- the run does not die (Next #1e)."""
     if torch.cuda.device_count() >= 2:
-        pytest.skip("box has several GPUs: RCCL would simply work")
+        pytest.skip("box has several GPUs: RCCL simply works -- the positive case is tests/test_gpu_multidevice.py::test_bench_two_ranks_on_two_devices_through_rccl[try-nccl]")
     args = ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--regions", "3", "--no-per-qtype", "--no-per-mode", "--cpu-seconds", "2", "--no-workloads", "--pairs", "4"]
     proc = _run(2, args, timeout=800, backend="try-nccl")
     (line,) = [json.loads(ln) for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -150,7 +150,7 @@ def test_rccl_failure_falls_back_to_gloo_fences_and_says_so():
 def test_bench_refuses_n_ranks_on_fewer_devices():
     """Without the rig an N-GPU line must come from N devices: 2 ranks on this 1-GPU box are refused before anything is timed."""
     if torch.cuda.device_count() >= 2:
-        pytest.skip("box has several GPUs")
+        pytest.skip("box has several GPUs: two ranks on two devices are accepted -- tests/test_gpu_multidevice.py::test_bench_two_ranks_on_two_devices_through_rccl[None]")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("GGQ_BENCH_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),

@@ -389,10 +389,8 @@ def _fake_comfy():
     return fake_comfy.build()
 
 
-@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
-def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
-    """With install() applied, the reference's own GGMLOps.Linear still runs end to end; CPU-resident
-    weights keep flowing through the reference's original functions (the HIP path only takes GPU data)."""
+def _reference_modules(monkeypatch):
+    """The reference's real dequant.py / ops.py imported as ``refpkg.*`` over the fake comfy."""
     reference.ensure_gguf()
     for k, v in _fake_comfy().items():
         monkeypatch.setitem(sys.modules, k, v)
@@ -406,7 +404,102 @@ def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
         monkeypatch.setitem(sys.modules, f"refpkg.{name}", m)
         spec.loader.exec_module(m)
         mods[name] = m
-    rd, ro = mods["dequant"], mods["ops"]
+    return mods["dequant"], mods["ops"]
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_install_default_policy_and_vram_accounting(pkg, monkeypatch):
+    """Round 5: (1) the default install turns the no-VRAM opt-ins on, ``exact`` / GGQ_EXACT turns them off, contradictions and ``fast`` without
+    ``ref_ops`` raise; (2) options that HOLD device memory make the reference's fake state dict (GGMLLayer.ggml_save_to_state_dict, ops.py:145-160:
+    what ComfyUI sizes a GGUF model by) grow by exactly ``scratch_reservation(...)["total"]`` on the largest layer -- and a default install by 0."""
+    rd, ro = _reference_modules(monkeypatch)
+    inst, Q = pkg.install, pkg.qtypes.Q
+    for v in ("GGQ_FAST", "GGQ_EXACT", "GGQ_FUSED_SMALL_M", "GGQ_FUSED_MFMA", "GGQ_GATHER_EMBEDDING", "GGQ_DENSE_CACHE_GB", "GGQ_OVERLAP"):
+        monkeypatch.delenv(v, raising=False)
+    rows, cols = 8, 512
+    blocks = pkg.synth.make_blocks(Q.Q4_K, rows * cols // 256, seed=3)
+    lin = ro.GGMLOps.Linear(cols, rows)
+    lin.weight = torch.nn.Parameter(ro.GGMLTensor(torch.from_numpy(blocks.reshape(-1).copy()), tensor_type=Q.Q4_K, tensor_shape=torch.Size((rows, cols))), requires_grad=False)
+    lin.bias = None
+    lin.largest_layer = True                                             # what ggml_load_from_state_dict sets for loader.py:134-137's tensor
+    small = ro.GGMLOps.Linear(cols, rows)
+    small.weight, small.bias = lin.weight, None
+    reference_save = ro.GGMLLayer.ggml_save_to_state_dict
+
+    def fake_bytes(layer):
+        sd = layer.state_dict()
+        assert all(t.device.type == "meta" for t in sd.values())
+        return sum(t.numel() * t.element_size() for t in sd.values()), set(sd)
+
+    packed_bytes, dense_bytes = blocks.size, rows * cols * 2
+    base, base_keys = fake_bytes(lin)
+    assert base == packed_bytes + dense_bytes and base_keys == {"weight", "temp.weight"}      # the reference's own estimate
+    # (1) policy
+    assert inst.DEFAULT_FAST is True
+    inst.install(rd, ro)
+    try:
+        assert inst._installed[id(rd)]["options"] == {"fused_small_m": True, "fused_mfma": 256, "gather_embedding": True}
+        assert hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__") and hasattr(ro.GGMLOps.Embedding.forward_ggml_cast_weights, "__wrapped__")
+        assert ro.GGMLLayer.ggml_save_to_state_dict is reference_save and fake_bytes(lin) == (base, base_keys)      # holds nothing: reserves nothing
+        assert inst.scratch_reservation(rd, dense_bytes, packed_bytes) == {"dense_cache": 0, "overlap": 0, "total": 0}
+        assert "GGQ_EXACT=1" in inst.describe(rd)
+    finally:
+        inst.uninstall(rd)
+    assert not hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__")
+    inst.install(rd)                                                      # functions only: nothing above them to fuse
+    assert inst._installed[id(rd)]["options"] == {}
+    inst.uninstall(rd)
+    for kw, env in (({"exact": True}, {}), ({}, {"GGQ_EXACT": "1"}), ({}, {"GGQ_FAST": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        inst.install(rd, ro, **kw)
+        opts = inst._installed[id(rd)]["options"]
+        assert not hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__") and "fused_small_m" not in opts
+        assert ("exact" in opts) == ("GGQ_FAST" not in env)
+        assert ("exact=True" if "exact" in opts else "bit-exact unpack + F.linear") in inst.describe(rd)
+        inst.uninstall(rd)
+        for k in env:
+            monkeypatch.delenv(k)
+    inst.install(rd, ro, exact=True, fused_small_m=True)                  # an option asked for by name wins over the switch
+    assert inst._installed[id(rd)]["options"] == {"fused_small_m": True, "exact": True}
+    inst.uninstall(rd)
+    with pytest.raises(ValueError):
+        inst.install(rd, ro, fast=True, exact=True)
+    with pytest.raises(ValueError):
+        inst.install(rd, fast=True)                                       # ADVICE round 4: used to be ignored silently
+    monkeypatch.setenv("GGQ_FAST", "1")
+    with pytest.raises(ValueError):
+        inst.install(rd)
+    monkeypatch.delenv("GGQ_FAST")
+    assert id(rd) not in inst._installed and rd.dequantize_tensor.__module__ == rd.__name__
+    # (2) accounting
+    for options, want in (({"dense_cache_gb": 2}, 2 * 10 ** 9), ({"overlap": True}, 2 * dense_bytes + 3 * packed_bytes),
+                          ({"dense_cache_gb": 0.5, "overlap": True}, 5 * 10 ** 8 + 2 * dense_bytes + 3 * packed_bytes)):
+        inst.install(rd, ro, exact=True, **options)
+        try:
+            assert ro.GGMLLayer.ggml_save_to_state_dict.__wrapped__ is reference_save
+            assert inst.scratch_reservation(rd, dense_bytes, packed_bytes)["total"] == want
+            got, keys = fake_bytes(lin)
+            assert got == base + want and keys == base_keys | {"temp.ggq_scratch"}, options
+            assert fake_bytes(small) == (packed_bytes, {"weight"})        # only the largest layer carries the reservation (like temp.weight)
+            assert inst.scratch_bytes(rd)["total"] == 0                   # nothing is HELD yet: the reservation is the worst case, up front
+        finally:
+            inst.uninstall(rd)
+        assert ro.GGMLLayer.ggml_save_to_state_dict is reference_save and fake_bytes(lin) == (base, base_keys)
+    # dequant_dtype float32: the reference's temp.weight is fp32 (ops.py:156) and so are overlap's dense slots
+    lin.dequant_dtype = torch.float32
+    inst.install(rd, ro, exact=True, overlap=True)
+    try:
+        assert fake_bytes(lin)[0] == packed_bytes + 2 * dense_bytes + (2 * 2 * dense_bytes + 3 * packed_bytes)
+    finally:
+        inst.uninstall(rd)
+
+
+@pytest.mark.skipif(not reference.available(), reason="/root/reference not present (GPU box)")
+def test_install_keeps_reference_behaviour_on_cpu(pkg, monkeypatch):
+    """With install() applied, the reference's own GGMLOps.Linear still runs end to end; CPU-resident
+    weights keep flowing through the reference's original functions (the HIP path only takes GPU data)."""
+    rd, ro = _reference_modules(monkeypatch)
     Q = pkg.qtypes.Q
     blocks = pkg.synth.make_blocks(Q.Q4_K, 8 * 2, seed=21)                 # weight 8 x 512
     weight = ro.GGMLTensor(torch.from_numpy(blocks.reshape(-1).copy()), tensor_type=Q.Q4_K, tensor_shape=torch.Size((8, 512)))
@@ -534,61 +627,6 @@ def test_bench_median_and_min_helper():
     assert reps == 10 and len(calls) == 13 and 0.001 <= tmin <= med < 0.05          # >= 3 warm-up, >= 10 timed passes, median and min
     med, tmin, reps = bench._median_min(lambda: time.sleep(0.001), budget_s=0.05, min_reps=3, warmup=0)
     assert 20 <= reps <= 200                                                         # ... and as many as the time budget allows
-
-
-def test_lookahead_bookkeeping_on_cpu(pkg, monkeypatch):
-    """lookahead.DequantAhead with a counting stand-in for the batch launch (no GPU): the learnt order, one launch per `depth`
-    layers, results handed out once and only for the very call that was predicted (object, in-place version, dtype, stream), a
-    changed order or a written-to weight recomputed on the spot, dead tensors forgotten."""
-    import gc
-    L = pkg.lookahead
-    T, Q = pkg.ops.GGMLTensor, pkg.qtypes.Q
-    plain, batches = [], []
-
-    def fn(tensor, dtype=None, dequant_dtype=None):
-        plain.append(id(tensor))
-        return torch.full(tuple(getattr(tensor, "tensor_shape", tensor.shape)), float(len(plain)), dtype=dtype)
-
-    def launch(items, stream, index):
-        batches.append([id(t) for t, _ in items])
-        return [torch.full(tuple(t.tensor_shape), -float(len(batches)), dtype=m[0]) for t, m in items]
-
-    ahead = L.DequantAhead(3, fn, launch_batch=launch)
-    # a CPU tensor is "not served here": make the eligibility test say yes without a GPU
-    monkeypatch.setattr(L.DequantAhead, "_mode_of", lambda self, t, dtype, dd: (dtype, dd, 0) if getattr(t, "tensor_type", None) is not None else None)
-    monkeypatch.setattr(L.DequantAhead, "_packed_ok", staticmethod(lambda t: True))
-    monkeypatch.setattr(L._dq, "_raw_stream", lambda index: 7)
-    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
-    mk = lambda: T(torch.zeros(288, dtype=torch.uint8), tensor_type=Q.Q4_K, tensor_shape=(2, 256))
-    ws = [mk() for _ in range(7)]
-    for w in ws:                                                   # pass 1: nothing known, one plain launch per layer
-        ahead(w, torch.float16)
-    assert len(plain) == 7 and not batches
-    outs = [ahead(w, torch.float16) for w in ws]                   # pass 2: the order is known (6 -> 0 from the first call of this pass on)
-    assert batches == [[id(ws[0]), id(ws[1]), id(ws[2])], [id(ws[3]), id(ws[4]), id(ws[5])], [id(ws[6]), id(ws[0]), id(ws[1])]] and len(plain) == 7
-    assert [float(o.flatten()[0]) for o in outs] == [-1, -1, -1, -2, -2, -2, -3]
-    st = ahead.stats()
-    assert st["hits"] == 4 and st["launches"] == 7 + 3 and st["tensors_in_batches"] == 9
-    assert st["held_bytes"] == ahead.scratch_bytes() == 2 * 2 * 256 * 2                  # the last batch ran into the next pass: two weights held
-    del batches[:]
-    outs = [ahead(w, torch.float16) for w in ws]                   # pass 3: 0 and 1 are there already
-    assert batches == [[id(ws[2]), id(ws[3]), id(ws[4])], [id(ws[5]), id(ws[6]), id(ws[0])]] and len(plain) == 7
-    assert ahead.stats()["hits"] == 4 + 5 and ahead.scratch_bytes() == 2 * 256 * 2
-    # what was unpacked ahead is handed out ONCE, and only to the call that was predicted
-    ws[0].add_(1)                                                  # in-place write into the packed bytes: its pending result is stale
-    n_plain, n_b = len(plain), len(batches)
-    ahead(ws[0], torch.float16)
-    assert ahead.stats()["stale_dropped"] == 1 and (len(batches) == n_b + 1 or len(plain) == n_plain + 1)
-    assert float(ahead(ws[1], torch.bfloat16).flatten()[0]) != float(outs[1].flatten()[0]) and ahead.stats()["stale_dropped"] >= 2   # another dtype than predicted
-    # a tensor that is not served (no tensor_type: an F32 bias, say) goes to the plain function and leaves the learnt order alone
-    n_plain = len(plain)
-    ahead(torch.zeros(4), torch.float16)
-    assert len(plain) == n_plain + 1 and ahead.stats()["bypassed"] == 1 and ahead._prev is not None
-    # dead tensors take their entries (and what was unpacked for them) along
-    tracked = ahead.stats()["tracked"]
-    del ws, w, outs
-    gc.collect()
-    assert ahead.stats()["tracked"] == 0 and tracked >= 7 and ahead.scratch_bytes() == 0
 
 
 def test_q4_k_exhaustive_generator_covers_what_it_says(pkg):

@@ -6,7 +6,8 @@
 
 Defines the sources understand (csrc/ggq_capi.hip): GGQ_SOLO_ONLY (one-wave teams everywhere), GGQ_COOP_ALL_MODES (workgroup
 teams everywhere), GGQ_SOLO_CAST_OUT (one-wave teams whenever the output is not fp16), GGQ_CAST_SOLO_AT_LAYER_SIZE (... also for
-single layers).  The variant goes through
+single layers); csrc/ggq_device.hpp: GGQ_F32_PAIR_MODE=0|1|2 (fp32 output: decode every chunk twice / swap halves in workgroup teams only /
+in every team); csrc/ggq_capi.hip: GGQ_F32_COOP_ALL, GGQ_Q2K_G32=<log2 run>, GGQ_Q2K_NT_LOADS.  The variant goes through
 the same FMA guard as the shipped build.  Keep variants out of comfyui-gguf_amd/_lib/ and out of git (*.so is ignored)."""
 import argparse
 import importlib
@@ -20,9 +21,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _objects_without_defines(nat, cache):
+    """The translation units the -D flags of an A/B build do not reach (GGUF reader, fused linears, side-stream prefetch), compiled once per
+    source state into ``cache`` and shared by every variant."""
+    import hashlib
+    os.makedirs(cache, exist_ok=True)
+    h = hashlib.sha256(" ".join(nat.HIPCC_FLAGS).encode())
+    for path in nat.SOURCES[1:] + nat.HEADERS:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    tag = h.hexdigest()[:12]
+    objs, jobs = [], []
+    flags = [f for f in nat.HIPCC_FLAGS if f != "-shared"]
+    for src in nat.SOURCES[1:]:
+        obj = os.path.join(cache, f"{os.path.splitext(os.path.basename(src))[0]}.{tag}.o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append((obj, subprocess.Popen([nat.hipcc_path()] + flags + ["-c", "-o", obj + ".tmp", src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for obj, proc in jobs:
+        _, err = proc.communicate()
+        if proc.returncode:
+            sys.exit(err[-4000:])
+        os.replace(obj + ".tmp", obj)
+    return objs
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--all-sources", action="store_true", help="pass the -D flags to every translation unit (default: to csrc/ggq_capi.hip, which holds "
+                                                               "every dequant kernel and its launch geometry; the other three are compiled once and shared)")
     args, defines = ap.parse_known_args()
     bad = [d for d in defines if not d.startswith("-D")]
     if bad:
@@ -32,7 +60,17 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="ggq_variant_") as tmp:
         lib = os.path.join(tmp, "lib.so")
-        cmd = [nat.hipcc_path()] + nat.HIPCC_FLAGS + defines + ["-save-temps=obj", "-o", lib] + nat.SOURCES
+        stamp = [f'-DGGQ_BUILD_ID="{nat.source_id()}+{"".join(defines)}"']
+        if args.all_sources:
+            cmd = [nat.hipcc_path()] + nat.HIPCC_FLAGS + defines + stamp + ["-save-temps=obj", "-o", lib] + nat.SOURCES
+        else:
+            shared = _objects_without_defines(nat, os.path.join(os.path.dirname(out), ".obj"))
+            obj = os.path.join(tmp, "ggq_capi.o")
+            compile_flags = [f for f in nat.HIPCC_FLAGS if f != "-shared"]
+            proc = subprocess.run([nat.hipcc_path()] + compile_flags + defines + stamp + ["-save-temps=obj", "-c", "-o", obj, nat.SOURCES[0]], cwd=tmp, capture_output=True, text=True)
+            if proc.returncode:
+                sys.exit(proc.stderr[-4000:])
+            cmd = [nat.hipcc_path()] + nat.HIPCC_FLAGS + ["-o", lib, obj] + shared
         proc = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         if proc.returncode:
             sys.exit(proc.stderr[-4000:])

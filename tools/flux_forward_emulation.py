@@ -35,7 +35,6 @@ def main():
     ap.add_argument("--dense-cache-gb", type=float, default=0.0, help="opt-in resident.DenseCache budget (0 = off, the reference's behaviour)")
     ap.add_argument("--fused-small-m", action="store_true", help="opt-in fused dequantize + linear for the 1-row (modulation) layers")
     ap.add_argument("--fused-mfma", type=int, default=0, metavar="MAX_M", help="opt-in fused dequantize + GEMM on the matrix cores for inputs of up to MAX_M rows")
-    ap.add_argument("--lookahead", type=int, default=0, metavar="K", help="opt-in: the next K - 1 layers' unpacks ride in the launch of the one asked for (lookahead.DequantAhead)")
     ap.add_argument("--overlap", action="store_true", help="opt-in side-stream prefetch of the next layer's weight (overlap.LayerPrefetcher)")
     ap.add_argument("--graph", action="store_true", help="also time both steps replayed from a captured HIP graph: GPU time without the host's issue rate")
     ap.add_argument("--lowvram", action="store_true", help="packed weights live on the CPU and are copied per layer per forward (ops.py:209)")
@@ -69,10 +68,6 @@ def main():
         cache = pkg.resident.DenseCache(args.dense_cache_gb * 1e9, pkg.dequant.dequantize_tensor)
         pkg.ops.GGMLLayer._dequantize = staticmethod(cache)
 
-    ahead = None
-    if args.lookahead > 1:
-        ahead = pkg.lookahead.DequantAhead(args.lookahead, pkg.dequant.dequantize_tensor)
-        pkg.ops.GGMLLayer._dequantize = staticmethod(ahead)
 
     prefetcher = None
     if args.overlap:
@@ -135,7 +130,6 @@ def main():
         "gemm_TFLOPs_dense": round(flops / d_med / 1e9, 1),
         "dense_cache": cache.stats() if cache is not None else None,
         "overlap": prefetcher.stats() if prefetcher is not None else None, "lowvram": args.lowvram,
-        "lookahead": ahead.stats() if ahead is not None else None,
         "dense_weight_GB": round(n_el * 2 / 1e9, 1), "packed_weight_GB": round(sum(lin.weight.numel() for lin, _ in layers) / 1e9, 2)}))
 
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--formats", default="", help="comma-separated subset (default: all)")
     ap.add_argument("--arith", action="store_true", help="also the bf16 / fp32 arithmetic modes")
+    ap.add_argument("--outs", default="f16,bf16,f32", help="comma-separated subset of the output dtypes")
     args = ap.parse_args()
     pkg = load_package()
     dev = torch.device("cuda:0")
@@ -39,6 +40,8 @@ def main():
         row = {}
         for cd in ((torch.float16, torch.bfloat16, torch.float32) if args.arith else (torch.float16,)):
             for od in (torch.float16, torch.bfloat16, torch.float32):
+                if names[od] not in args.outs.split(","):
+                    continue
                 p = pkg.grouped.DequantPlan([(d, q, sh) for d, sh in zip(base._keep, shapes)], out_dtype=od, dequant_dtype=cd)
                 ms, _ = bench.timed_steps(p, args.steps, 3, dev, lambda: torch.cuda.synchronize(dev))
                 row[f"{names[cd]}->{names[od]}"] = round(p.bytes / (ms / args.steps * 1e-3) / 1e9, 1)
