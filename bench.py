@@ -42,6 +42,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -250,6 +251,71 @@ def with_ceiling(roofline, ceiling, read_bytes, write_bytes):
                      "blend_mix": {"read_share": round(r / (r + w), 4), "write_share": round(w / (r + w), 4)},
                      "blend_how": "copy part (2 x read bytes at measured copy rate) + fill part (write - read bytes at measured fill rate); " + ceiling["measured_how"]})
     return roofline
+
+
+class GpuTelemetry:
+    """Clocks, power and temperature of the GPU while a leg runs: `rocm-smi --json` sampled once a second from a helper thread (the launching thread is
+    never interrupted).  What it is for: the in-context cost is a difference of two long steps and moved 0.65 -> 2.4 ms from box to box in round 4; the
+    line now says what the silicon was doing meanwhile.  ``summary()`` is None when rocm-smi is not there or prints nothing usable."""
+
+    def __init__(self, device, period_s=1.0):
+        self.index = torch.device(device).index or 0
+        self.period, self.samples, self._stop, self._thread = period_s, [], None, None
+
+    def _sample(self):
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=10).stdout
+            card = next(iter(json.loads(out).values()))
+        except Exception:                                              # noqa: BLE001 -- telemetry must never fail the bench
+            return None
+        row = {}
+        for k, v in card.items():
+            kl = k.lower()
+            m = re.search(r"-?\d+(?:\.\d+)?", str(v).split("(")[-1] if "clock" in kl else str(v))
+            if not m:
+                continue
+            x = float(m.group(0))
+            if "sclk" in kl and "clock speed" in kl:
+                row["sclk_MHz"] = x
+            elif "mclk" in kl and "clock speed" in kl:
+                row["mclk_MHz"] = x
+            elif "power" in kl and "socket" in kl or "average graphics package power" in kl:
+                row["power_W"] = x
+            elif "temperature" in kl and "junction" in kl:
+                row["junction_C"] = x
+            elif "temperature" in kl and ("hbm" in kl or "mem" in kl) and "hbm_C" not in row:
+                row["hbm_C"] = x
+        return row or None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                r = self._sample()
+                if r:
+                    self.samples.append(r)
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=15)
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        out = {"samples": len(self.samples), "source": "rocm-smi --showclocks --showpower --showtemp --json, 1 Hz while the legs ran"}
+        for k in ("sclk_MHz", "mclk_MHz", "power_W", "junction_C", "hbm_C"):
+            v = [s[k] for s in self.samples if k in s]
+            if v:
+                out[k] = {"min": min(v), "mean": round(sum(v) / len(v), 1), "max": max(v)}
+        return out
 
 
 def per_launch_stats(plan, reps, device):
@@ -813,11 +879,25 @@ def run_per_layer(pkg, args, device, fence):
         for w, x in zip(dense, layer_x):
             lin(x, w)
 
-    (d_ms, _), d_regs = median(step_dense, 3)
-    ctx = {"tokens": tokens, "ms_per_step_dense_resident": round(d_ms, 3), "dense_regions_ms": d_regs}
-    for policy, fn in (("shipped_sc1", dq), ("streaming_nt", dq_stream)):
-        (q_ms, _), regs = median(step_with(fn), 3)
-        ctx[policy] = {"ms_per_step": round(q_ms, 3), "dequant_cost_ms_per_step": round(q_ms - d_ms, 3), "regions_ms": regs}
+    # The cost is a DIFFERENCE of two ~70 ms steps, so a 1 % drift of the GPU's clock between the two legs reads as 0.7 ms (rounds 3-4 measured the dense leg
+    # first, then the quantized ones: 0.65-2.4 ms across boxes).  Since round 5 the three legs are INTERLEAVED region by region (dense, sc1, nt, dense, ...), each
+    # reported as the median of its regions, and the GPU's clocks / power are sampled beside them (rocm-smi, once a second, off the launching thread).
+    legs = {"dense": step_dense, "shipped_sc1": step_with(dq), "streaming_nt": step_with(dq_stream)}
+    for fn in legs.values():
+        fn()
+        fn()
+    seen = {k: [] for k in legs}
+    with GpuTelemetry(device) as tele:
+        for _ in range(max(3, args.regions)):
+            for k, fn in legs.items():
+                seen[k].append(region(fn, 3)[0])
+    med = {k: sorted(v)[len(v) // 2] for k, v in seen.items()}
+    d_ms = med["dense"]
+    ctx = {"tokens": tokens, "ms_per_step_dense_resident": round(d_ms, 3), "dense_regions_ms": [round(v, 5) for v in seen["dense"]],
+           "how": "dense / sc1 / nt regions interleaved (3 steps each), medians; cost = median(leg) - median(dense)", "gpu_telemetry": tele.summary()}
+    for policy in ("shipped_sc1", "streaming_nt"):
+        ctx[policy] = {"ms_per_step": round(med[policy], 3), "dequant_cost_ms_per_step": round(med[policy] - d_ms, 3), "regions_ms": [round(v, 5) for v in seen[policy]],
+                       "cost_by_region_ms": [round(q - d, 3) for q, d in zip(seen[policy], seen["dense"])]}
     del dense
     torch.cuda.empty_cache()
 

@@ -29,7 +29,7 @@ using namespace ggq;
 //     per-wave fixed cost dominates -- and a team holds its wave slots idle while it finds its tensor, which is why the
 //     coop teams get the coarse index (run_many below): before it, coop LOST up to 3.5 % on Q5_K / Q5_0 / Q6_K.
 //   * non-temporal stores (+3.4 %; the other cache-policy bits make no difference); non-temporal loads are a wash for
-//     the 4/5/8-bit formats and cost 2-4 % on Q2_K / Q3_K / Q6_K, so those three use plain loads.
+//     the 4/5/8-bit formats and cost 2-4 % on Q3_K / Q6_K, so those two use plain loads (Q2_K too in rounds 1-4; re-measured in round 5).
 //   * XCD-aware workgroup -> group mapping on LARGE launches (profiles/r01_microbench_l_xcd_run_mapping.txt): inside each
 //     tile every XCD takes a run of consecutive groups covering 256 KiB of fp16 output (64 solo groups, 32 coop groups)
 //     instead of every eighth group: +1.2...+2.2 % at bench.py level; -4 % for Q2_K / Q3_K and -1.5 % for Q5_1 (identity
@@ -41,8 +41,9 @@ using namespace ggq;
 // Measurement knobs (environment, read once): GGQ_XRUN_LOG2, GGQ_LDS_PAD force one value for every format.
 template <class F> struct PadOf { static constexpr uint32_t V = 0; };
 template <> struct PadOf<FmtQ6_K> { static constexpr uint32_t V = 4096; };
-template <class F> struct PlainLoads { static constexpr bool V = false; };    // non-temporal loads cost these three 2-4 %
-#ifndef GGQ_Q2K_NT_LOADS    /* A/B builds define it */
+template <class F> struct PlainLoads { static constexpr bool V = false; };    // non-temporal loads cost these 2-4 %
+#ifdef GGQ_Q2K_PLAIN_LOADS  /* A/B builds only: rounds 1-4.  With the buffer-store path non-temporal loads are +1.0...1.5 % for Q2_K in both alternations
+                               (profiles/r05_mode_table_q2k_shapes.json), so it follows the general rule now */
 template <> struct PlainLoads<FmtQ2_K> { static constexpr bool V = true; };
 #endif
 template <> struct PlainLoads<FmtQ3_K> { static constexpr bool V = true; };
@@ -91,9 +92,6 @@ template <class F> struct Tune : TuneCoop<F> {};
 //       format      G   coop  waves  log2(run)
 GGQ_TUNE(FmtQ3_K,    8,  false, 1,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    6);
-#ifdef GGQ_Q2K_G32          /* A/B builds only: Q2_K teams of 4 waves x 8192 elements on whole-model launches too; the value is log2(run) */
-GGQ_TUNE(FmtQ2_K,    32, true,  4,    GGQ_Q2K_G32);
-#endif
 #undef GGQ_TUNE
 
 // The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
@@ -123,33 +121,50 @@ template <> struct CoopForOut<FmtQ5_K, OUT_BF16> { static constexpr bool V = fal
 template <> struct CoopForOut<FmtIQ4_NL, OUT_BF16> { static constexpr bool V = false; };
 template <> struct CoopForOut<FmtIQ4_XS, OUT_BF16> { static constexpr bool V = false; };
 #endif
-// The rule so far -- coop for the fp16 arithmetic (minus the bf16-output exceptions), solo for the other arithmetic modes except
-// Q8_0 / Q4_1 -- and the cells where an all-coop against an all-solo build, alternated twice on one box over all 12 x 9 cells
-// (profiles/r01_mode_table_all_coop_vs_all_solo.json), says otherwise by more than 1.5 % in both alternations:
+// The rule: workgroup teams for the fp16 arithmetic (minus the bf16-output exceptions), one-wave teams for the other arithmetic modes except Q8_0 / Q4_1;
+// fp32 OUTPUT always takes the workgroup teams (round 5: with one decode per chunk and the halves swapped inside lane pairs -- ggq_device.hpp pair_f32 --
+// the workgroup shape wins or is level in every arithmetic mode: mean of the 36 fp32-output cells 6147 GB/s against 6006 for the round-4 table,
+// profiles/r05_mode_table_f32out_pairing_and_teams.json; that one rule replaces seven per-cell exceptions).  The cells where an all-coop against an all-solo
+// build, alternated twice on one box over all 12 x 9 cells (profiles/r01_mode_table_all_coop_vs_all_solo.json), says otherwise by more than 1.5 % in both
+// alternations stay listed:
 template <class F, int ARITH, int OUT> struct UseCoop {
-#ifdef GGQ_F32_COOP_ALL     /* A/B builds only: workgroup teams for every fp32-output cell */
-    static constexpr bool V = OUT == OUT_F32 || ((ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V);
-#else
+#ifdef GGQ_F32_TEAMS_R4     /* A/B builds only: fp32 output follows the arithmetic's team shape, as in rounds 1-4 (minus that table's per-cell exceptions) */
     static constexpr bool V = (ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V;
+#else
+    static constexpr bool V = OUT == OUT_F32 || ((ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V);
 #endif
 };
-#if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES) && !defined(GGQ_F32_COOP_ALL)
+#if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES)
 #define GGQ_TEAM(F, AR, OUT_, COOP_) template <> struct UseCoop<F, AR, OUT_> { static constexpr bool V = COOP_; }
-GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F16, false);     // coop -4.1 %  (bf16 arithmetic: -1.1 % with the other two outputs, taken along)
+GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F16, false);     // coop -4.1 %  (bf16 arithmetic: -1.1 % with bf16 output, taken along)
 GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_BF16, false);
-GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F32, false);
 GGQ_TEAM(FmtQ5_1, AR_BF16, OUT_BF16, true);     // coop +1.8 %
-GGQ_TEAM(FmtQ5_1, AR_BF16, OUT_F32, true);      //      +3.3 %
 GGQ_TEAM(FmtQ5_1, AR_F32, OUT_F16, true);       //      +3.6 %
 GGQ_TEAM(FmtQ5_1, AR_F32, OUT_BF16, true);      //      +4.5 %
-GGQ_TEAM(FmtQ5_1, AR_F32, OUT_F32, true);       //      +6.1 %
-GGQ_TEAM(FmtQ4_K, AR_BF16, OUT_F32, true);      //      +2.8 %  (fp32 output doubles the store rows per wave: coop halves them again)
-GGQ_TEAM(FmtQ5_K, AR_BF16, OUT_F32, true);      //      +6.8 %
-GGQ_TEAM(FmtQ5_K, AR_F32, OUT_F32, true);       //      +2.6 %
-GGQ_TEAM(FmtIQ4_NL, AR_BF16, OUT_F32, true);    //      +1.8 %
 #undef GGQ_TEAM
 #endif
-template <class F, int ARITH, int OUT> struct TuneFor : std::conditional<!Tune<F>::COOP || UseCoop<F, ARITH, OUT>::V, Tune<F>, TuneSolo<F>>::type {};
+// fp32 output writes twice the bytes per element: a workgroup team's 4096 elements would be FOUR 1-KiB store rows per wave, and a pure fill already runs
+// 5 % slower with four rows per wave than with two (profiles/r01_microbench_q_stream_ceilings_rows_policy_mapping.txt).  So teams of 2048 elements there -- two
+// rows per wave, as for the 2-byte outputs -- wherever the per-chunk arithmetic is light enough that one chunk per thread still hides its latency: the fp16
+// arithmetic (packed ops; the stock loader) of every format, and the 32-element legacy blocks in every arithmetic.  Same-box alternation against the
+// 4096-element teams (profiles/r05_mode_table_f32out_half_group.json): f16->f32 Q4_0 +6 %, Q4_1 +8 %, Q5_1 +6 %, Q8_0 +5 %, Q4_K / Q2_K +3 %, level for Q5_K /
+// IQ4_NL; f32->f32 legacy blocks +3...+6 %; the K-quants in bf16 / fp32 arithmetic lose 1-10 % with it and keep 4096.
+template <class T> struct HalfGroup : T { static constexpr int G = T::G / 2; };
+#if defined(GGQ_F32_FULL_GROUP)      /* A/B builds only */
+template <class F, int ARITH, int OUT> struct HalfForF32 { static constexpr bool V = false; };
+#else
+template <class F, int ARITH, int OUT> struct HalfForF32 { static constexpr bool V = OUT == OUT_F32 && (ARITH == AR_F16 || F::BS == 32); };
+#endif
+template <class F, int ARITH, int OUT> struct CoopShape : std::conditional<HalfForF32<F, ARITH, OUT>::V, HalfGroup<Tune<F>>, Tune<F>>::type {};
+// The two formats whose 2-byte outputs run in one-wave teams: with fp32 output (8 store rows per wave there) Q6_K gains 5-8 % in workgroup teams of 2048 elements in every
+// arithmetic, Q3_K loses 2-6 % and stays (same-box alternation, profiles/r05_mode_table_f32out_q3k_q6k_workgroup_teams.json).
+template <class F> struct CoopForF32Only { static constexpr bool V = false; };
+#ifndef GGQ_Q6K_F32_SOLO             /* A/B builds define it */
+template <> struct CoopForF32Only<FmtQ6_K> { static constexpr bool V = true; };
+#endif
+template <class F, int ARITH, int OUT> struct TuneFor
+    : std::conditional<!Tune<F>::COOP, typename std::conditional<OUT == OUT_F32 && CoopForF32Only<F>::V, HalfGroup<TuneCoop<F>>, Tune<F>>::type,
+                       typename std::conditional<UseCoop<F, ARITH, OUT>::V, CoopShape<F, ARITH, OUT>, TuneSolo<F>>::type>::type {};
 
 constexpr uint64_t XRUN_MIN_ELEMENTS = 1ull << 27;   // 134 M elements: whole-model plans, not single FLUX layers (<= 66 M)
 // ... for the one-wave teams.  The workgroup teams need the run mapping more (identity costs them 8 % on the 3 G-element pool)
@@ -323,37 +338,28 @@ struct Segment {
 
 
 // ---- ggq_calibrate: what THIS memory system gives a stream with no arithmetic at all, measured by the product library itself so that bench.py
-// can put the figure in the same JSON line as the dequant kernels' (roofline.measured_*).  Launched like the dequant kernels: one-shot workgroups of
-// 4 waves, each wave instruction covering 1 KiB of contiguous memory (16 B per lane), 8 KiB per workgroup (two rows per wave), no grid-stride loop
-// (a persistent loop is 10-30 % slower on this part for fills: a wave's next store row waits behind vmcnt for the previous one's acknowledgement).
+// can put the figure in the same JSON line as the dequant kernels' (roofline.measured_*).  The shape is the fastest stream the round-1 sweeps found on
+// this part (profiles/r01_microbench_q_stream_ceilings_rows_policy_mapping.txt): one-shot workgroups of 4 waves, ONE 16-byte access per lane -- each wave
+// instruction covers 1 KiB of contiguous memory, a workgroup 4 KiB -- with the dequant engine's XCD run mapping at 2^6 (every XCD writes runs of 256 KiB);
+// a grid-stride loop is 10-30 % slower for fills (a wave's next store row waits behind vmcnt for the previous one's acknowledgement).
 // KIND: 0 fill, 1 fill with non-temporal stores, 2 copy, 3 copy with non-temporal loads and stores, 4 read-only (the loaded words are folded into
 // one value that is stored only if it equals a constant -- once in 2^32 threads on random data, into the caller's scratch).
 template <int KIND>
 __global__ __launch_bounds__(256) void calibrate_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, uint64_t n16)
 {
-    const uint64_t base = (uint64_t)blockIdx.x * 512ull + (threadIdx.x >> 6) * 128ull + (threadIdx.x & 63);   // wave w: rows 2w and 2w + 1 of the workgroup's 8
-    uint32_t acc = 0;
-    u32x4 v[2];
-    if constexpr (KIND >= 2) {
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const uint64_t i = base + 64ull * r;
-            v[r] = u32x4{0u, 0u, 0u, 0u};
-            if (i < n16) v[r] = (KIND == 2) ? in[i] : __builtin_nontemporal_load(in + i);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const uint64_t i = base + 64ull * r;
-        if (i >= n16) continue;
-        if constexpr (KIND == 0) out[i] = u32x4{(uint32_t)i, 1u, 2u, 3u};
-        else if constexpr (KIND == 1) __builtin_nontemporal_store(u32x4{(uint32_t)i, 1u, 2u, 3u}, out + i);
-        else if constexpr (KIND == 2) out[i] = v[r];
-        else if constexpr (KIND == 3) __builtin_nontemporal_store(v[r], out + i);
-        else acc ^= v[r].x ^ v[r].y ^ v[r].z ^ v[r].w;
-    }
-    if constexpr (KIND == 4) {
-        if (acc == 0x9E3779B9u) out[threadIdx.x] = u32x4{acc, acc, acc, acc};
+    uint32_t bid = blockIdx.x;
+    constexpr uint32_t XR = 6, TL = XR + 3u;
+    const uint32_t tile = bid >> TL, inside = bid & ((1u << TL) - 1u);
+    if (((tile + 1) << TL) <= gridDim.x) bid = (tile << TL) + ((inside & 7u) << XR) + (inside >> 3);
+    const uint64_t i = (uint64_t)bid * 256ull + threadIdx.x;
+    if (i >= n16) return;
+    if constexpr (KIND == 0) out[i] = u32x4{(uint32_t)i, 1u, 2u, 3u};
+    else if constexpr (KIND == 1) __builtin_nontemporal_store(u32x4{(uint32_t)i, 1u, 2u, 3u}, out + i);
+    else if constexpr (KIND == 2) out[i] = in[i];
+    else if constexpr (KIND == 3) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+    else {
+        const u32x4 v = __builtin_nontemporal_load(in + i);
+        if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9E3779B9u) out[threadIdx.x] = v;
     }
 }
 
@@ -468,7 +474,7 @@ int ggq_calibrate(int kind, const void* src, void* dst, uint64_t bytes, void* hi
     if (!dst || (kind >= GGQ_CAL_COPY && !src) || (bytes & 15u) != 0 || (kind == GGQ_CAL_READ && bytes < 4096)) return GGQ_ERR_ARG;
     if (!aligned16(dst) || (src && !aligned16(src))) return GGQ_ERR_ALIGN;
     const uint64_t n16 = bytes / 16;
-    const uint64_t blocks = (n16 + 511) / 512;
+    const uint64_t blocks = (n16 + 255) / 256;
     if (blocks > MAX_GRID) return GGQ_ERR_ARG;
     const uint32_t grid = (uint32_t)blocks;
     const u32x4* in = static_cast<const u32x4*>(src);

@@ -592,8 +592,11 @@ GGQ_DEV void emit(const Fields& f, int piece, gptr out, uint64_t elem)
 //     store 1 (first KiB):  even lane <- its own quad 0,  odd lane <- the even lane's quad 1      -> chunk c, contiguous
 //     store 2 (second KiB): even lane <- the odd lane's quad 0,  odd lane <- its own quad 1       -> chunk c + 32
 // With fp16 arithmetic the halves cross as packed fp16 pairs (2 dwords) and are widened afterwards (v_cvt_f32_f16, exact).
-#ifndef GGQ_F32_PAIR_MODE       /* A/B builds: 0 = never (the rounds 1-4 layout), 1 = workgroup teams only, 2 = every team */
-#define GGQ_F32_PAIR_MODE 2
+// Measured (tools/mode_table.py --arith --outs f32, five builds alternated twice on one box, profiles/r05_mode_table_f32out_pairing_and_teams.json): in the
+// workgroup teams the swap is worth +2...+8 % on the formats with a real decode (Q4_0, Q5_0, the K-quants, IQ4_*), level on Q4_1 / Q8_0; in the one-wave
+// teams (8 store rows per wave, no partner wave to hide the exchange behind) it LOSES 3-10 % -- so: workgroup teams swap, one-wave teams keep decoding twice.
+#ifndef GGQ_F32_PAIR_MODE       /* A/B builds: 0 = never (the rounds 1-4 layout), 1 = workgroup teams only (shipped), 2 = every team */
+#define GGQ_F32_PAIR_MODE 1
 #endif
 
 GGQ_DEV uint32_t swap_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }

@@ -1,0 +1,47 @@
+"""The rule install()'s default stands on (Next #1): on FLUX.1-dev / SD3.5-large / T5-xxl linear shapes the fused dequantize + linear
+kernels are NO FURTHER from an fp64 evaluation on the oracle's weights than the default path (bit-exact unpack + F.linear), and reproduce run to run.
+The full table (every distinct shape x {1, 4, 64, 256} rows x {bf16, fp16}) is profiles/r05_fused_error.json, produced by the same function
+(tools/fused_error.py measure()); here a sample of the shapes runs in every `pytest -m gpu`."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool():
+    spec = importlib.util.spec_from_file_location("fused_error", os.path.join(ROOT, "tools", "fused_error.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_fused_linears_are_no_further_from_fp64_than_unpack_plus_f_linear(pkg):
+    T = _tool()
+    every = T.linear_shapes(pkg)
+    # one shape per (model, kernel-relevant geometry): FLUX modulation (18432x3072, the 1-row case), FLUX proj, SD3.5 fc2 (cols 9728), SD3.5 qkv (Q5_0, cols 2432:
+    # the MFMA kernel declines it), T5 ffn_down (cols 10240)
+    pick = [s for s in every if (s[3], s[4]) in ((18432, 3072), (3072, 3072), (2432, 9728), (7296, 2432), (4096, 10240))]
+    assert len(pick) == 5
+    out = T.measure(pkg, torch.device("cuda:0"), ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), shapes=pick)
+    s = out["summary"]
+    assert s["cases"] == 40 and s["fused_ran"] == 36 and s["declined"] == 4            # SD3.5 qkv at 64 / 256 rows: cols % 256 != 0
+    assert s["fused_nondeterministic"] == 0
+    assert s["worst_rms_ratio_fused_over_default"] <= 1.02, s
+    assert s["worst_max_excess_in_output_ulps"] <= 1.0, s
+    assert s["min_same_bits_share"] >= 0.98, s                                         # and in fact almost every output is the very same number
+    assert s["fused_no_worse"] is True
+    for c in out["cases"]:
+        if c.get("fused"):
+            assert c["fused"] == ("ggq_linear_small" if c["m"] <= 4 else "ggq_linear_mfma")
+
+
+def test_the_committed_table_says_what_the_default_claims():
+    """profiles/r05_fused_error.json is what install.DEFAULT_FAST cites: it must cover all three models and carry the verdict."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_fused_error.json")))
+    assert d["summary"]["fused_no_worse"] is True and d["summary"]["cases"] == 128
+    assert {c["model"] for c in d["cases"]} == {"flux", "sd35", "t5"} and {c["m"] for c in d["cases"]} == {1, 4, 64, 256}

@@ -192,7 +192,7 @@ def test_reference_layers_with_overlap(mods, pkg, dev, resident):
              H.make_linear(ro, pkg, Q.Q8_0, 48, 1024, wdev, seed=5, dequant_dtype="target")[0], H.make_linear(ro, pkg, Q.IQ4_NL, 32, 512, wdev, seed=6)[0]]
     xs = [torch.randn(17, lin.in_features, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(i)) for i, lin in enumerate(chain)]
     want = [lin(x) for lin, x in zip(chain, xs)]
-    with H.Installed(pkg, mods, overlap="all"):
+    with H.Installed(pkg, mods, overlap=True):
         pf = pkg.install.prefetcher(mods["dequant"])
         for _ in range(4):
             for lin, x, w in zip(chain, xs, want):
@@ -201,7 +201,11 @@ def test_reference_layers_with_overlap(mods, pkg, dev, resident):
         st = pf.stats()
     # 4 eligible layers per pass; the patched one breaks the chain, so the layer after it is never predicted, and the wrap-around
     # (last layer -> first layer) is only learnt at the start of pass 2: hits 0 + 2 + 3 + 3, misses 4 + 2 + 1 + 1
-    assert st["bypassed"] == 4 and st["hits"] == 8 and st["misses"] == 8 and st["mispredicted"] == 0
+    if resident:
+        # weights already in HBM are left alone (round 5: the switch that prefetched those too measured slower in every run and is gone from install())
+        assert st["bypassed"] == 20 and st["hits"] == 0 and st["misses"] == 0
+    else:
+        assert st["bypassed"] == 4 and st["hits"] == 8 and st["misses"] == 8 and st["mispredicted"] == 0
     assert pkg.install.prefetcher(mods["dequant"]) is None and ro.GGMLLayer.cast_bias_weight.__name__ == "cast_bias_weight"
 
 

@@ -7,7 +7,7 @@
 Defines the sources understand (csrc/ggq_capi.hip): GGQ_SOLO_ONLY (one-wave teams everywhere), GGQ_COOP_ALL_MODES (workgroup
 teams everywhere), GGQ_SOLO_CAST_OUT (one-wave teams whenever the output is not fp16), GGQ_CAST_SOLO_AT_LAYER_SIZE (... also for
 single layers); csrc/ggq_device.hpp: GGQ_F32_PAIR_MODE=0|1|2 (fp32 output: decode every chunk twice / swap halves in workgroup teams only /
-in every team); csrc/ggq_capi.hip: GGQ_F32_COOP_ALL, GGQ_Q2K_G32=<log2 run>, GGQ_Q2K_NT_LOADS.  The variant goes through
+in every team); csrc/ggq_capi.hip: GGQ_F32_TEAMS_R4, GGQ_F32_HALF_GROUP, GGQ_Q2K_PLAIN_LOADS.  The variant goes through
 the same FMA guard as the shipped build.  Keep variants out of comfyui-gguf_amd/_lib/ and out of git (*.so is ignored)."""
 import argparse
 import importlib

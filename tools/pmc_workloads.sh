@@ -4,6 +4,6 @@
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for W in flux sd35-t5; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcw/$W-$C -o p -- python $R/bench.py --workload $W --steps 2 --warmup 1 --regions 1 --cpu-seconds 0 > $R/gpurun_out/pmcw/$W-$C.log 2>&1 || echo "$W $C failed: $(tail -2 $R/gpurun_out/pmcw/$W-$C.log)"
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcw/$W-$C -o p -- python $R/bench.py --workload $W --steps 2 --warmup 1 --regions 1 --cpu-seconds 0 --no-ceiling > $R/gpurun_out/pmcw/$W-$C.log 2>&1 || echo "$W $C failed: $(tail -2 $R/gpurun_out/pmcw/$W-$C.log)"
   done
 done
