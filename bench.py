@@ -31,6 +31,7 @@ Other workloads (not the driver's default; same JSON contract, one line):
   --workload sd35-t5     BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors (549 tensors), same treatment.
   --workload flux-gguf   the FLUX weight set written to a synthetic .gguf file, then parsed by the native
                          reader, streamed file -> pinned -> HBM and dequantized: the PCIe-inclusive rate.
+  --workload fused-error the numerics table behind install()'s default (tools/fused_error.py): fused linears vs unpack + F.linear against fp64; not a throughput line.
   --workload per-layer   the FLUX weight set the way the node drives it (ops.py:177): one dequantize_tensor() launch per tensor, bf16
                          result -- standalone (graph-replayed, both store policies), eager, in context (unpack + F.linear per layer vs
                          dense-resident weights), and the reference's own eager torch ops on the same device tensors beside it.
@@ -962,6 +963,22 @@ def run_per_layer(pkg, args, device, fence):
     return line
 
 
+def run_fused_error(pkg, device):
+    """--workload fused-error: NOT a throughput line -- the numerics table install()'s default stands on (tools/fused_error.py measure(): fused linears vs
+    unpack + F.linear, both against an fp64 product on the oracle's weights, every linear shape of FLUX.1-dev / SD3.5-large / T5-xxl x {1, 4, 64, 256} rows x
+    {bf16, fp16}).  `value` = the worst RMS-error ratio fused / default over all cases (1.0 = equal, lower is better)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fused_error", os.path.join(ROOT, "tools", "fused_error.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    out = tool.measure(pkg, device)
+    s = out["summary"]
+    return {"metric": "worst RMS-error ratio, fused dequantize+linear / (unpack + F.linear), both vs an fp64 product on the oracle's weights", "value": s["worst_rms_ratio_fused_over_default"],
+            "unit": "ratio", "n_gpus": 1, "steps": s["cases"], "warmup": 0, "ms_per_step": None, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "bf16+f16",
+            "data": "synthetic", "config": {"workload": "fused-error: every distinct linear shape of FLUX.1-dev / SD3.5-large / T5-xxl x {1,4,64,256} rows x {bf16,f16}", "summary": s},
+            "cases": out["cases"], "roofline": None, "cpu_baseline": None}
+
+
 def median_region(pkg, plan, args, W, regions, steps=None, warmup=None):
     """`regions` timed regions of exactly K launches each (the first after W warm-up launches), every one bracketed by the
     fence on both sides and reduced with MAX over ranks; the reported step time is the MEDIAN region's.  Returns
@@ -990,7 +1007,7 @@ def main():
     ap.add_argument("--regions", type=int, default=3, help="timed regions of K steps each; the median region is reported")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured fill / copy / read ceilings (ggq_calibrate) beside the spec peak")
     ap.add_argument("--no-workloads", action="store_true", help="skip the configs[3] / configs[4] sub-lines of the default run")
-    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer"], help="see the module docstring")
+    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer", "fused-error"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
     ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf / per-layer: only the first N tensors (smoke runs, tests)")
@@ -1047,6 +1064,10 @@ def main():
             result = run_flux(pkg, args, W)
             if result is not None:
                 result["world"] = world_info
+        elif args.workload == "fused-error":
+            if world != 1:
+                sys.exit("--workload fused-error is a single-GPU measurement")
+            result = run_fused_error(pkg, device)
         elif args.workload == "per-layer":
             if world != 1:
                 sys.exit("--workload per-layer is a single-GPU measurement")

@@ -52,9 +52,11 @@ GGQ_DEV h2 bcast_hi(h2 v) { return __builtin_shufflevector(v, v, 1, 1); }
 // and (1024 + q) - (1024 + bias) is an exact fp16 subtraction -> int -> fp16 without v_cvt.
 constexpr uint32_t MAGIC = 0x64006400u;
 
-// bytes (b0,b1) of w -> 16-bit lanes [b0, b1]; bytes (b2,b3) -> [b2, b3]   (v_perm_b32)
-GGQ_DEV uint32_t spread_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C010C00u); }
-GGQ_DEV uint32_t spread_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0C030C02u); }
+// bytes (b0,b1) of w -> 16-bit lanes [0x64:b0, 0x64:b1]; bytes (b2,b3) -> [0x64:b2, 0x64:b3]: the SAME v_perm_b32 that spreads the bytes also supplies the
+// 0x64 exponent byte of the magic (its other source operand holds 0x64 in every byte; selector 4 = that operand's byte 0), so `spread | MAGIC` is one
+// instruction, not two (round 5: 4 VALU fewer per chunk in every fp16-arithmetic kernel -- 46 -> 42 per 8 weights in ggq_linear_small, which is VALU-bound).
+GGQ_DEV uint32_t spread_lo_magic(uint32_t w) { return __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u); }
+GGQ_DEV uint32_t spread_hi_magic(uint32_t w) { return __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u); }
 
 // two small unsigned ints (bits 0.. and 16..) -> h2 of (q - bias), exact
 GGQ_DEV h2 ints_h2(uint32_t pair, float bias) { return as_h2(pair | MAGIC) - splatf(1024.0f + bias); }
@@ -106,11 +108,16 @@ GGQ_DEV u32x2 lds_ld8(const uint8_t* p)
     }
 }
 
-// 4 byte-fields t (one per byte, value < 1024 after OR-ing `extra`) -> two h2 of (field - bias)
+// 4 byte-fields t (one per byte) -> two h2 of (field - bias), exact
 struct H2x2 { h2 a, b; };
 GGQ_DEV H2x2 fields_h2(uint32_t t, float bias)
 {
-    return H2x2{ints_h2(spread_lo(t), bias), ints_h2(spread_hi(t), bias)};
+    const h2 off = splatf(1024.0f + bias);
+#ifdef GGQ_PERM_THEN_OR     /* A/B builds only: rounds 1-4 (zero-extend with v_perm_b32, then v_or_b32 the magic in) */
+    return H2x2{as_h2(__builtin_amdgcn_perm(0u, t, 0x0C010C00u) | MAGIC) - off, as_h2(__builtin_amdgcn_perm(0u, t, 0x0C030C02u) | MAGIC) - off};
+#else
+    return H2x2{as_h2(spread_lo_magic(t)) - off, as_h2(spread_hi_magic(t)) - off};
+#endif
 }
 
 // 4 bits of x (bit k -> bit 0 of byte k)

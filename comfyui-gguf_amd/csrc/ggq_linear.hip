@@ -61,6 +61,8 @@ hipError_t launch(const void* packed, const void* x, const void* bias, void* y, 
     per_cu = per_cu > wps ? wps : (per_cu < 1u ? 1u : per_cu);
     static const int lab_per_cu = lab_int("GGQ_LIN_PER_CU", 1, 8);   // lab builds only, read once (-1 in the shipped library)
     if (lab_per_cu >= 1 && (uint32_t)lab_per_cu < per_cu) per_cu = (uint32_t)lab_per_cu;
+    // (Equal shares -- every wave the same number of rows, fewer waves than the chip holds -- measured 5-10 % SLOWER than filling every wave slot and letting a
+    // quarter of the waves run one row more: the extra waves hide more latency than the uneven tail costs.  profiles/r05_fused_linear_small_grid_shares.json)
     const uint32_t grid = need < cus * per_cu ? need : cus * per_cu;
     if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
         static std::atomic<uint64_t> raised{0};

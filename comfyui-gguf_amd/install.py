@@ -254,7 +254,7 @@ def _gather_embedding(embedding_cls, unsupported):
 
     def forward_ggml_cast_weights(self, input, out_dtype=None):
         weight = self.weight
-        if (input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
+        if (not _hip._is_compiling() and input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
                 and not getattr(weight, "patches", None)):
             # the table's dtype the reference's way: out_dtype, else what cast_bias_weight(self, ...) falls back to (ops.py:196-197)
             table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
@@ -278,7 +278,9 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
 
     def forward_ggml_cast_weights(self, input):
         weight = self.weight
-        if weight is not None and input.is_cuda:
+        # torch.compile traces the REFERENCE's method only (its unpack is the opaque custom op ggq::dequantize, dequant.py): a fused kernel behind a
+        # ctypes call is nothing Dynamo can put in a graph, and a graph break per layer would cost more than the fusion saves
+        if weight is not None and input.is_cuda and not _hip._is_compiling():
             cols = input.shape[-1]
             m = input.numel() // cols if cols else 0
             try:

@@ -443,6 +443,38 @@ def test_plan_mixed_qtypes_matches_per_tensor(pkg):
     plan.close(); plan2.close(); plan3.close()
 
 
+@pytest.mark.parametrize("name", ALL)
+def test_fp32_output_through_plans_ragged_and_large(pkg, name):
+    """Round 5: fp32 results decode every chunk ONCE and swap halves inside lane pairs (ggq_device.hpp pair_f32; workgroup teams of 2048 or 4096
+    elements depending on format and arithmetic, one-wave teams for Q3_K).  Whole plans -- the dequant_many kernels, groups that straddle a tensor's
+    end, a partner lane whose chunk lies past it, launches big enough for the XCD run mapping -- against the oracle, fp16 and fp32 arithmetic."""
+    q = pkg.qtypes.Q[name]
+    bs, ts = pkg.qtypes.block_geometry(q)
+    shapes = [(1, 256), (3, 256), (7, 768), (8, 256), (9, 256), (17, 512), (33, 256), (1024, 3072), (5, 1280)]
+    items, packed = [], []
+    for i, sh in enumerate(shapes):
+        p = pkg.synth.make_tensor_bytes(q, sh, seed=7700 + i, mode="signed")
+        packed.append(p)
+        items.append((torch.from_numpy(p).to(DEV), q, sh))
+    for compute in ("f16", "f32"):
+        plan = pkg.grouped.DequantPlan(items, out_dtype=torch.float32, dequant_dtype=None if compute == "f16" else torch.float32)
+        assert plan.kernels == 1
+        outs = plan.launch()
+        torch.cuda.synchronize()
+        for sh, p, out in zip(shapes, packed, outs):
+            assert out.dtype == torch.float32 and tuple(out.shape) == sh
+            if compute == "f16":
+                want = oracle.dequant_f16(q, p, simd=oracle.simd_available()).astype(np.float32)
+            else:
+                want = oracle.dequant_f32(q, p)
+            assert np.array_equal(_canon(_raw(out), "f32"), _canon(want, "f32")), (name, compute, sh)
+        plan.close()
+    # the per-tensor entry point on the big one (another team shape may be picked for a single tensor of this size): the same bits
+    one = pkg.dequant.dequantize_tensor(_carrier(pkg, packed[7].reshape(-1, ts), q), torch.float32)          # fp16 arithmetic, single-tensor launch
+    want = oracle.dequant_f16(q, packed[7], simd=oracle.simd_available()).astype(np.float32)
+    assert np.array_equal(_canon(_raw(one), "f32"), _canon(want, "f32")), name
+
+
 def test_large_plan_uses_the_xcd_run_mapping_and_stays_exact(pkg):
     """Launches of >= 65536 groups switch to the XCD-aware workgroup -> group mapping (a permutation of which
     workgroup does which group, ggq_capi.hip Tune<>): every tensor of a 0.9 G-element two-format plan is

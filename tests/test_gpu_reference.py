@@ -327,13 +327,17 @@ def test_module_to_device_then_forward(mods, pkg, dev, monkeypatch):
                                                        torch.Tensor(lin.bias).to(dev, torch.bfloat16)))
 
 
-def test_torch_compile_through_reference_linear(mods, pkg, dev):
-    """The reference allows full compile on torch >= 2.8 (ops.py:20-42): Dynamo traces through its forward into our custom op."""
+@pytest.mark.parametrize("options", [{}, {"fast": True}], ids=["exact", "round-5-default"])
+def test_torch_compile_through_reference_linear(mods, pkg, dev, options):
+    """The reference allows full compile on torch >= 2.8 (ops.py:20-42): Dynamo traces through its forward into our custom op.  With the round-5
+    default (fused linears on) the compiled function still traces the REFERENCE's method -- the wrappers stand aside while compiling -- so the
+    compiled result is the exact path's, bit for bit, also for an input small enough for the fused kernels."""
     ro, Q = mods["ops"], pkg.qtypes.Q
     lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=41)
-    x = torch.randn(8, 512, device=dev, dtype=torch.float16)
+    x = torch.randn(8 if not options else 2, 512, device=dev, dtype=torch.float16)
     with H.Installed(pkg, mods):
         want = lin(x)
+    with H.Installed(pkg, mods, **options):
         try:
             fn = torch.compile(lambda t: lin(t), backend="eager")
             got = fn(x)
