@@ -85,6 +85,27 @@ template <> struct SharedScale<FmtQ5_K> { static constexpr bool V = true; };
 #ifndef GGQ_LIN_UNROLL2
 #define GGQ_LIN_UNROLL2 0      /* A/B builds */
 #endif
+// Sum over the 64 lanes of a wave, result in LANE 63 (and nowhere else): six v_add_f32 with DPP operands -- quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+// (every lane of a row of 16 then holds its row's sum), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- instead of a butterfly of six
+// ds_bpermute_b32 round trips through the LDS crossbar (what __shfl_xor compiles to), each a dependent ~100-cycle wait at the end of every row.
+template <int CTRL, int ROWS>
+GGQ_DEV float dpp_f(float v)        // lanes of rows outside ROWS read 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+#define GGQ_DPP_ADD(V, CTRL, ROWS) V += dpp_f<CTRL, ROWS>(V)
+GGQ_DEV float wave_sum_lane63(float v)
+{
+    GGQ_DPP_ADD(v, 0xB1, 0xF);       // quad_perm [1,0,3,2]
+    GGQ_DPP_ADD(v, 0x4E, 0xF);       // quad_perm [2,3,0,1]
+    GGQ_DPP_ADD(v, 0x141, 0xF);      // row_half_mirror
+    GGQ_DPP_ADD(v, 0x140, 0xF);      // row_mirror
+    GGQ_DPP_ADD(v, 0x142, 0xA);      // row_bcast:15 -> rows 1, 3 (the other rows add 0)
+    GGQ_DPP_ADD(v, 0x143, 0xC);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#undef GGQ_DPP_ADD
+
 constexpr int LIN_NU_MAX = 6;                    // 16-byte load units per lane per row: rows of up to 6128 packed bytes
 constexpr int LIN_SLICE = LIN_NU_MAX * 64 * 16;  // the LARGEST LDS slice a wave can need for one row (+ up to 15 bytes of leading misalignment)
 constexpr int LIN_WAVES = 4;
@@ -199,9 +220,14 @@ __global__ __launch_bounds__(LIN_WAVES * 64) GGQ_LIN_OCC void linear_small(const
         wave_sync();                                                      // the slice is rewritten at the top of the loop
 #pragma unroll
         for (int mm = 0; mm < M; mm++) {
+#ifdef GGQ_LIN_REDUCE_BPERMUTE      /* A/B builds only: the rounds 2-4 butterfly */
             float v = acc[mm];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+#else
+            const float v0 = wave_sum_lane63(acc[mm]);
+            float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 63));      // wave-uniform: lane 0 stores it
+#endif
             if (lane == 0) {
                 if (bias_ != nullptr) {
                     float b;
