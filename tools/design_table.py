@@ -43,6 +43,30 @@ def rel(path):
     return os.path.relpath(path, ROOT)
 
 
+BYTES_PER_ELEMENT_IN = {"Q4_0": 18 / 32, "Q4_1": 20 / 32, "Q5_0": 22 / 32, "Q5_1": 24 / 32, "Q8_0": 34 / 32, "Q2_K": 84 / 256, "Q3_K": 110 / 256, "Q4_K": 144 / 256,
+                        "Q5_K": 176 / 256, "Q6_K": 210 / 256, "IQ4_NL": 18 / 32, "IQ4_XS": 136 / 256}
+POOL_ELEMENTS = 64 * (3072 * 3072 + 3072 * 12288)
+
+
+def traffic_span(tr, modes):
+    """PMC bytes / algorithmic bytes over the pool entries of pmc_traffic.json: the formats (fp16 result) or Q4_K's other modes; outliers above 1 % are named."""
+    ratios = {}
+    for key, val in tr.items():
+        parts = key.split(":")
+        if len(parts) < 2 or parts[1] != "pairs64" or parts[0] not in BYTES_PER_ELEMENT_IN:
+            continue
+        if modes != (len(parts) == 3):
+            continue
+        out_bytes = 4 if (len(parts) == 3 and parts[2].endswith("->f32")) else 2
+        ratios[parts[0] if not modes else parts[2]] = val / (POOL_ELEMENTS * (BYTES_PER_ELEMENT_IN[parts[0]] + out_bytes))
+    if not ratios:
+        return "—"
+    usual = [r for r in ratios.values() if r < 1.01]
+    odd = ", ".join(f"{k} {r:.3f}" for k, r in ratios.items() if r >= 1.01)
+    span = f"{min(usual):.4f}–{max(usual):.4f}" if usual else ""
+    return f"{span} ({len(ratios)} measured" + (f"; {odd}: two XCDs fetch the line two groups share" if odd else "") + ")"
+
+
 def headline_table(d, tr, src):
     pq, pm, w = d["per_qtype"], d["per_mode"], d["workloads"]
     rf = d["roofline"]
@@ -57,10 +81,10 @@ def headline_table(d, tr, src):
                     f"blend for the headline's {100 * rf['blend_mix']['read_share']:.0f} % read / {100 * rf['blend_mix']['write_share']:.0f} % write mix: {rf['blend_ceiling_GBps']:.0f} | — | — |")
     rows.append("| per format → fp16: " + ", ".join(f"{k} {v['GB/s']:.0f}" for k, v in pq.items())
                 + f" | {min(v['GB/s'] for v in pq.values()):.0f}–{max(v['GB/s'] for v in pq.values()):.0f} | "
-                  f"{min(v['pct_hbm_peak'] for v in pq.values()) / 100:.2f}–{max(v['pct_hbm_peak'] for v in pq.values()) / 100:.2f} | 1.0001–1.0009 (Q3_K 1.127 on reads) |")
+                  f"{min(v['pct_hbm_peak'] for v in pq.values()) / 100:.2f}–{max(v['pct_hbm_peak'] for v in pq.values()) / 100:.2f} | {traffic_span(tr, modes=False)} |")
     rows.append("| Q4_K, other (arithmetic→out) modes: " + ", ".join(f"{k} {v['GB/s']:.0f}" for k, v in pm.items())
                 + f" | {min(v['GB/s'] for v in pm.values()):.0f}–{max(v['GB/s'] for v in pm.values()):.0f} | "
-                  f"{min(v['pct_hbm_peak'] for v in pm.values()) / 100:.2f}–{max(v['pct_hbm_peak'] for v in pm.values()) / 100:.2f} | 1.0000–1.0005 |")
+                  f"{min(v['pct_hbm_peak'] for v in pm.values()) / 100:.2f}–{max(v['pct_hbm_peak'] for v in pm.values()) / 100:.2f} | {traffic_span(tr, modes=True)} |")
     for k, lab in (("flux", "FLUX.1-dev Q4_K_M weight set (304 tensors, 2 launches)"), ("sd35-t5", "SD3.5-large + T5-XXL Q4_K_M (549 tensors, 3 launches)")):
         r = w[k]["roofline"]
         t = tr.get(k + ":Q4_K_M")
