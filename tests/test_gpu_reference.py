@@ -239,6 +239,38 @@ def test_reference_linear_fused_small_m(mods, pkg, dev, monkeypatch):
         assert counter.n == n + 6
 
 
+def test_default_install_is_the_fast_one_and_exact_is_bit_equal(mods, pkg, dev, monkeypatch):
+    """Round 5: ``install(ref_dequant, ref_ops)`` with NO option = fused kernels for 1-4 rows and for <= 256 rows, the reference's method (unpack + F.linear,
+    bit for bit) above that, for fp32 activations and for LoRA-patched layers; ``exact=True`` = the reference's output bit for bit at every row count."""
+    ro, Q, inst = mods["ops"], pkg.qtypes.Q, pkg.install
+    for v in ("GGQ_FAST", "GGQ_EXACT", "GGQ_FUSED_SMALL_M", "GGQ_FUSED_MFMA", "GGQ_GATHER_EMBEDDING", "GGQ_FUSED_MFMA_MAX_M"):
+        monkeypatch.delenv(v, raising=False)
+    lin, packed = H.make_linear(ro, pkg, Q.Q4_K, 96, 1024, dev, seed=14)
+    lora, _ = H.make_linear(ro, pkg, Q.Q4_K, 96, 1024, dev, seed=14, patches=H.lora_patch((96, 1024), seed=16))
+    xs = {m: torch.randn(m, 1024, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(50 + m)) for m in (1, 3, 64, 256, 257)}
+    want = {m: lin(x) for m, x in xs.items()}                            # the reference's own torch ops on this GPU
+    want_lora = lora(xs[3])
+    w64 = H.oracle_tensor(Q.Q4_K, packed, torch.bfloat16, None, (96, 1024)).double()
+    counter = H.LaunchCounter(pkg, monkeypatch)
+    inst.install(mods["dequant"], mods["ops"])                           # no option at all
+    try:
+        assert inst._installed[id(mods["dequant"])]["options"] == {"fused_small_m": True, "fused_mfma": 256, "gather_embedding": True}
+        for m in (1, 3, 64, 256):
+            got = lin(xs[m])
+            assert counter.n == 0, f"m = {m}: the fused kernels read the packed weight themselves"
+            ref = xs[m].cpu().double() @ w64.T + torch.Tensor(lin.bias).cpu().double()
+            tol = 1024 * 2.0 ** -24 * (xs[m].cpu().double().abs() @ w64.abs().T) + 2.0 ** -8 * ref.abs() + 1e-30
+            assert bool(((got.cpu().double() - ref).abs() <= tol).all()), m
+            assert float((got == want[m]).double().mean()) > 0.97         # and almost every output is the very number F.linear gives
+        assert torch.equal(lin(xs[257]), want[257]) and counter.n == 1   # above 256 rows: unpack + F.linear, bit for bit
+        assert torch.equal(lora(xs[3]), want_lora) and counter.n == 2    # LoRA-patched: the reference's method
+    finally:
+        inst.uninstall(mods["dequant"])
+    with H.Installed(pkg, mods, exact=True):
+        for m, x in xs.items():
+            assert torch.equal(lin(x), want[m]), m
+
+
 def test_reference_linear_fused_mfma(mods, pkg, dev, monkeypatch):
     """install(fused_mfma=True): up to fused_mfma_max_m rows go through the MFMA kernel (tolerance vs fp64 on the oracle's weights);
     more rows, fp32 inputs and LoRA-patched layers keep the reference's method bit for bit."""
