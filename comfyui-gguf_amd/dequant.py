@@ -329,15 +329,23 @@ def dequantize_tensor_via_gpu(tensor, dtype=None, dequant_dtype=None, device=Non
 
 
 import os as _os
-_CHECK_INDICES = _os.environ.get("GGQ_CHECK_INDICES", "0") not in ("", "0")
 
 
-def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
+def _check_indices_default(dropin):
+    """GGQ_CHECK_INDICES: 1 / 0 forces / forbids the asynchronous device-side assert on token ids outside the table.  Unset: ON when the call stands in for
+    ``F.embedding`` under install() (the reference fails on such an id -- a tokenizer / vocabulary mismatch -- and so must the drop-in), OFF for direct calls
+    of this function (the kernel clamps)."""
+    v = _os.environ.get("GGQ_CHECK_INDICES")
+    return dropin if v is None or v == "" else v != "0"
+
+
+def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None, check_indices=None):
     """``F.embedding(indices, dequantize_tensor(tensor, dtype, dequant_dtype))`` without unpacking the whole table: only the
     rows ``indices`` names are dequantized (include/ggq.h ``ggq_dequant_rows``), bit-identical values.  What
     ``GGMLOps.Embedding.forward_ggml_cast_weights`` computes (ops.py:251-260) in two steps.  ``tensor``: quantized, logical
     shape (n_rows, cols), GPU-resident; ``indices``: integer tensor on the same device; result: indices.shape + (cols,).
-    Raises GGQUnsupported for anything else (the caller keeps dequantize_tensor + F.embedding)."""
+    Raises GGQUnsupported for anything else (the caller keeps dequantize_tensor + F.embedding).  Ids outside the table are CLAMPED by the kernel;
+    ``check_indices`` adds the device-side assert ``F.embedding`` would raise (default: GGQ_CHECK_INDICES, else off here / on under install())."""
     qtype = getattr(tensor, "tensor_type", None)
     key = qtype if qtype in _HIP_TABLE else _qtype_key(qtype)
     if key not in _HIP_TABLE:
@@ -361,9 +369,9 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None):
         if data.numel() != n_rows * (cols // block_size) * type_size:
             raise GGQUnsupported("row lookup: packed bytes do not match the logical shape")
         idx = indices if (indices.dtype is torch.int64 and indices.is_contiguous()) else indices.to(torch.int64).contiguous()
-        if _CHECK_INDICES:
-            # F.embedding raises a device-side assert on an id outside the table; the kernel clamps.  GGQ_CHECK_INDICES=1 restores the failure
-            # (asynchronously, like torch's own assert) for debugging a tokenizer / vocabulary mismatch.
+        if _check_indices_default(False) if check_indices is None else check_indices:
+            # F.embedding raises a device-side assert on an id outside the table; the kernel clamps.  The check restores the failure
+            # (asynchronously, like torch's own assert): on by default under install(), where this call stands in for F.embedding.
             torch._assert_async(((idx >= 0) & (idx < n_rows)).all(), "ggq: token id outside the embedding table")
         out = torch.empty(tuple(indices.shape) + (cols,), dtype=out_dtype, device=data.device)
         n_idx = idx.numel()

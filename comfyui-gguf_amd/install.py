@@ -249,8 +249,9 @@ def _account_scratch(layer_cls, rec):
 
 def _gather_embedding(embedding_cls, unsupported):
     """Wrap ``embedding_cls.forward_ggml_cast_weights``; returns the (owner, name, original) record uninstall() restores."""
-    from .dequant import dequantize_rows
+    from .dequant import _check_indices_default, dequantize_rows
     reference_forward = embedding_cls.forward_ggml_cast_weights
+    check = _check_indices_default(True)           # the reference's F.embedding fails on an id outside the table: so does the drop-in (GGQ_CHECK_INDICES=0: clamp)
 
     def forward_ggml_cast_weights(self, input, out_dtype=None):
         weight = self.weight
@@ -259,7 +260,7 @@ def _gather_embedding(embedding_cls, unsupported):
             # the table's dtype the reference's way: out_dtype, else what cast_bias_weight(self, ...) falls back to (ops.py:196-197)
             table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
             try:
-                return dequantize_rows(weight.to(input.device), input, table_dtype, self.dequant_dtype).to(dtype=out_dtype)
+                return dequantize_rows(weight.to(input.device), input, table_dtype, self.dequant_dtype, check_indices=check).to(dtype=out_dtype)
             except unsupported:
                 pass
         return reference_forward(self, input, out_dtype)

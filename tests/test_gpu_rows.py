@@ -110,10 +110,15 @@ def test_rows_limits(pkg):
     assert L.ggq_dequant_rows(int(Q.Q8_0), table.data_ptr() + 2, 8, 8, ids.data_ptr(), 4, got.data_ptr(), 0, 0, None) == nat.GGQ_ERR_ALIGN
 
 
-def test_install_gather_embedding_wraps_the_embedding_forward(pkg):
+def test_install_gather_embedding_wraps_the_embedding_forward(pkg, monkeypatch):
     """install(..., gather_embedding=True) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights`` (reference ops.py:251-260).  The
-    reference is not on the GPU box, so the wrapper is driven on a class with that method's shape."""
+    reference is not on the GPU box, so the wrapper is driven on a class with that method's shape.  Under install() the lookup keeps F.embedding's
+    error behaviour: an asynchronous device-side assert on ids outside the table (round 5: the option is part of the default install), unless GGQ_CHECK_INDICES=0."""
     Q, ops = pkg.qtypes.Q, pkg.ops
+    monkeypatch.delenv("GGQ_CHECK_INDICES", raising=False)
+    asserted = []
+    real_assert = torch._assert_async
+    monkeypatch.setattr(torch, "_assert_async", lambda cond, msg="": (asserted.append(msg), real_assert(cond, msg))[1])
 
     class Embedding(ops.GGMLLayer):
         calls = 0
@@ -140,6 +145,9 @@ def test_install_gather_embedding_wraps_the_embedding_forward(pkg):
             got = emb(ids, out_dtype=dt)
             assert got.dtype == ref.dtype and torch.equal(got, ref)
         assert Embedding.calls == before                                         # the row kernel served all of them
+        assert len(asserted) == 3 and all("outside the embedding table" in m for m in asserted)      # ... each with the id check F.embedding implies
+        pkg.dequant.dequantize_rows(table, ids, torch.float16)                   # a direct call of the library function: the kernel clamps, no check
+        assert len(asserted) == 3
         emb.max_norm = 1.0                                                       # renormalising lookups need the dense table
         emb(ids, out_dtype=torch.float16)
         assert Embedding.calls == before + 1
