@@ -162,7 +162,9 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     for (const MfmaEntry& c : MFMA)
         if (c.qtype == qtype) e = &c;
     if (!e) return GGQ_ERR_QTYPE;
-    if ((dtype != GGQ_F16 && dtype != GGQ_BF16) || cols == 0 || cols % (uint32_t)MF_SPAN != 0) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
+    // the contraction length: whole 256-element spans, or -- 32-element legacy blocks only -- a last span that is a multiple of 64 (SD3.5's 2432 columns)
+    const bool k_tail = cols % (uint32_t)MF_SPAN != 0;
+    if ((dtype != GGQ_F16 && dtype != GGQ_BF16) || cols == 0 || (k_tail && (e->block_size != 32 || cols % 64u != 0))) return GGQ_ERR_ARG;   // caller: dequantize + GEMM
     if (rows == 0 || m == 0) return GGQ_OK;
     if (!packed || !x || !y) return GGQ_ERR_ARG;
     if (!aligned16(packed) || !aligned16(x)) return GGQ_ERR_ALIGN;
@@ -177,12 +179,12 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
         // 84 tiles (21504 x 3072 at 256 rows) the shared tile by 13 %, 192+ tiles by 2x.  Whether ANY fused shape beats unpack + hipBLASLt is the
         // caller's question (fused.linear_mfma declines above 256 rows of x unless a tile is forced: profiles/r04_gemm_skeleton_sweep.json).
         const uint32_t n_tiles = ((m + GT_BM - 1) / GT_BM) * ((rows + GT_BN - 1) / GT_BN);
-        const bool tile_ok = m >= tile_min_m() && rows % 8u == 0 && rows <= (1u << 22) && aligned16(y) && n_tiles >= 80u;
+        const bool tile_ok = !k_tail && m >= tile_min_m() && rows % 8u == 0 && rows <= (1u << 22) && aligned16(y) && n_tiles >= 80u;
         shape = m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2));
     }
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
-    if (shape == 3 && (rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;          // 16-byte pieces of y; 32-bit offsets inside a tile's rows of y
+    if (shape == 3 && (k_tail || rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;   // whole spans only; 16-byte pieces of y; 32-bit offsets inside a tile's rows of y
     if (shape == 3 && !aligned16(y)) return GGQ_ERR_ALIGN;                                // the shared-tile epilogue stores 16-byte vectors
     const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
     return err == hipSuccess ? GGQ_OK : hip_fail(err);

@@ -15,7 +15,8 @@
 //
 // Shape of the work:
 //   * a workgroup owns a tile of MB*32 rows of x  x  32 rows of W (= 32 output columns); its 4 waves split K: wave w takes the
-//     256-element spans w, w+4, ... of the contraction (K % 256 == 0) and all of the tile, so every weight of the tile is
+//     256-element spans w, w+4, ... of the contraction (K % 256 == 0; for the 32-element legacy blocks also K % 64 == 0 with a shorter
+//     LAST span -- SD3.5's 2432-column layers -- round 5) and all of the tile, so every weight of the tile is
 //     decoded ONCE per workgroup; at the end the four partial accumulators are summed through LDS in a fixed order (deterministic);
 //   * per span a wave copies the span's packed bytes of its 32 weight rows (32 x 144 B for Q4_K) into its private LDS slice with
 //     16 B/lane loads -- the next span's bytes are already in flight in registers -- then runs 16 k-steps: decode one chunk
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
     const uint32_t n0 = blockIdx.x * 32u, m0 = blockIdx.y * (uint32_t)(MB * 32);
     const gcptr packed = (gcptr)packed_;
     const uint64_t row_bytes = (uint64_t)(cols / F::BS) * F::TS;
-    const uint32_t n_spans = cols / MF_SPAN;
+    const uint32_t n_spans = (cols + MF_SPAN - 1) / MF_SPAN;
+    const uint32_t tail_len = cols - (n_spans - 1) * (uint32_t)MF_SPAN;           // elements of the LAST span: 256, or a multiple of 64 below it (32-element blocks only)
+    auto span_len = [&](uint32_t span) { return span + 1 == n_spans ? tail_len : (uint32_t)MF_SPAN; };
     uint8_t* slice = smem + wave * PER_WAVE;
     uint8_t* xs = slice + G::SLICE;
 
@@ -113,8 +116,9 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             const uint32_t rr = (n0 + ur < n_rows) ? n0 + ur : n_rows - 1;
             const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
+            const uint32_t span_bytes = span_len(span) / (uint32_t)F::BS * (uint32_t)F::TS;       // == SPAN_BYTES but for a short last span
             // the last unit of a row may reach past the row's span by < 16 bytes inside its aligned 16-byte unit: same page, never faults
-            pf[u] = (ur < 32u && uu * 16u < a + (uint32_t)G::SPAN_BYTES) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
+            pf[u] = (ur < 32u && uu * 16u < a + span_bytes) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
         }
     };
 
@@ -154,8 +158,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
             const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
+            const uint32_t len = span_len(span);
 #pragma unroll
             for (int q = 0; q < 4; q++) {                                          // 64 contraction elements per q: k = 64 q + 32 h + 8 s .. + 7
+                if ((uint32_t)(q * 64) >= len) break;                              // a short last span (wave-uniform)
                 u32x4 xq[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) xq[s4] = *(GGQ_GLOBAL const u32x4*)(xrow + kbyte + (uint32_t)(q * 128 + s4 * 16));
@@ -187,7 +193,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
 #pragma unroll
             for (int i = 0; i < NX; i++) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
         };
-        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + MF_WAVES - 1) / MF_WAVES : 0u, my_pieces = my_spans * 8u;
+        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + MF_WAVES - 1) / MF_WAVES : 0u;
+        // 8 pieces of 32 elements per span; the wave that owns the LAST span has fewer in it when that span is short
+        const bool owns_last = my_spans > 0 && (uint32_t)wave + MF_WAVES * (my_spans - 1) == n_spans - 1;
+        const uint32_t my_pieces = my_spans * 8u - (owns_last ? (uint32_t)(MF_SPAN - tail_len) / 32u : 0u);
         if (my_pieces > 0) xfetch(0u, ring[0]);
         if (my_pieces > 1) xfetch(1u, ring[1]);
         uint32_t piece = 0;
@@ -198,8 +207,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
+            const uint32_t len = span_len(span);
 #pragma unroll
             for (int t = 0; t < 8; t++, piece++) {                                 // 32 contraction elements per t: k = 32 t + 16 h + 8 s .. + 7
+                if ((uint32_t)(t * 32) >= len) break;                              // a short last span (wave-uniform; it is the wave's last one)
 #pragma unroll
                 for (int i = 0; i < NX; i++) *reinterpret_cast<u32x4*>(xs + xdst[i]) = ring[t & 1][i];
                 wave_sync();

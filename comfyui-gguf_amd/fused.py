@@ -50,9 +50,11 @@ def _prepare(x, weight, bias, dequant_dtype, what, dtypes, need_cols_256):
     if len(shape) != 2:
         raise GGQUnsupported(f"{what}: 2-D weight")
     rows, cols = int(shape[0]), int(shape[1])
-    if (not x.is_cuda or x.dtype not in dtypes or x.shape[-1] != cols or cols == 0 or (need_cols_256 and cols % 256) or x.numel() == 0):
+    # the MFMA kernels contract whole 256-element spans; for the 32-element legacy blocks the LAST span may be a shorter multiple of 64 (SD3.5: 2432 columns)
+    k_ok = not need_cols_256 or cols % 256 == 0 or (ent[1] == 32 and cols % 64 == 0)
+    if (not x.is_cuda or x.dtype not in dtypes or x.shape[-1] != cols or cols == 0 or not k_ok or x.numel() == 0):
         raise GGQUnsupported(f"{what}: GPU tensors, {'fp16 / bf16' if need_cols_256 else 'fp16 / bf16 / fp32'} input of matching width"
-                             + (", cols % 256 == 0" if need_cols_256 else ""))
+                             + (", cols % 256 == 0 (32-element blocks: cols % 64 == 0)" if need_cols_256 else ""))
     m = x.numel() // cols
     xf = x if x.dim() == 2 else x.reshape(m, cols)
     if not xf.is_contiguous() or xf.data_ptr() & 15:
@@ -130,8 +132,8 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
     kernel) or ``auto_max_rows=None`` forces the fused kernel at any size."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
-    if tile_rows not in (0, 32, 64, 128, 256) or (tile_rows == 256 and rows % 8):
-        raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 32, 64, 128 or 256 (the shared-tile kernel, rows % 8 == 0)")
+    if tile_rows not in (0, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
+        raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 32, 64, 128 or 256 (the shared-tile kernel: rows % 8 == 0, cols % 256 == 0)")
     if tile_rows == 0 and auto_max_rows is not None and m > auto_max_rows:
         raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x -- above {auto_max_rows} rows dequantize + F.linear is the faster path; pass tile_rows= to force a fused shape")
     if _mfma_call is None:

@@ -184,14 +184,16 @@ void ggq_overlap_destroy(ggq_overlap* ov);
 int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
                      void* y, int dtype, void* hip_stream);
 
-/* ---- fused dequantize + GEMM on the matrix cores for many rows of x (opt-in; SURVEY.md section 8f item 4, large-m end) ---------- */
+/* ---- fused dequantize + GEMM on the matrix cores for many rows of x (large-m end) ---------------------- */
 
 /* y[m, rows] = x[m, cols] @ W^T (+ bias[rows]), W = dequantize_tensor(packed, dtype) of logical shape (rows, cols), any m >= 1, computed
  * from the packed blocks on v_mfma_f32_32x32x16_{f16,bf16}: each lane decodes the 8 consecutive weights that ARE its MFMA operand, the
- * dense weight never exists in memory.  x, bias, y of `dtype` in {GGQ_F16, GGQ_BF16}, contiguous, x 16-byte aligned; cols % 256 == 0
- * (GGQ_ERR_ARG otherwise: the caller keeps dequantize + GEMM).  tile_rows = rows of x per workgroup tile: 32 / 64 / 128 / 256, 0 = auto.
+ * dense weight never exists in memory.  x, bias, y of `dtype` in {GGQ_F16, GGQ_BF16}, contiguous, x 16-byte aligned; cols % 256 == 0 -- for the 32-element
+ * block formats cols % 64 == 0 suffices (a shorter last span; not with tile_rows 256) -- GGQ_ERR_ARG otherwise: the caller keeps dequantize + GEMM.
+ * tile_rows = rows of x per workgroup tile: 32 / 64 / 128 / 256, 0 = auto.
  * Weights bit-identical to the reference's, fp32 accumulation in the MFMA's order, K split over 4 waves and summed in a fixed order
- * (deterministic).  Replaces, opt-in: GGMLOps.Linear.forward_ggml_cast_weights (ops.py:242-244) = get_weight + F.linear. */
+ * (deterministic).  Replaces (install()'s default for up to 256 rows of x; `exact` turns it off): GGMLOps.Linear.forward_ggml_cast_weights
+ * (ops.py:242-244) = get_weight + F.linear. */
 int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
                     void* y, int dtype, int tile_rows, void* hip_stream);
 

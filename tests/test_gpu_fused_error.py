@@ -22,13 +22,14 @@ def _tool():
 def test_fused_linears_are_no_further_from_fp64_than_unpack_plus_f_linear(pkg):
     T = _tool()
     every = T.linear_shapes(pkg)
-    # one shape per (model, kernel-relevant geometry): FLUX modulation (18432x3072, the 1-row case), FLUX proj, SD3.5 fc2 (cols 9728), SD3.5 qkv (Q5_0, cols 2432:
-    # the MFMA kernel declines it), T5 ffn_down (cols 10240)
-    pick = [s for s in every if (s[3], s[4]) in ((18432, 3072), (3072, 3072), (2432, 9728), (7296, 2432), (4096, 10240))]
-    assert len(pick) == 5
+    # one shape per (model, kernel-relevant geometry): FLUX modulation (18432x3072, the 1-row case), FLUX proj, FLUX mlp.2 (cols 12288: a row wider than
+    # ggq_linear_small's LDS staging -- declined at 1 / 4 rows), SD3.5 fc2 (cols 9728), SD3.5 qkv (Q5_0, cols 2432 = 9.5 spans: the MFMA kernel's short
+    # last span), T5 ffn_down (cols 10240)
+    pick = [s for s in every if (s[3], s[4]) in ((18432, 3072), (3072, 3072), (3072, 12288), (2432, 9728), (7296, 2432), (4096, 10240))]
+    assert len(pick) == 6
     out = T.measure(pkg, torch.device("cuda:0"), ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), shapes=pick)
     s = out["summary"]
-    assert s["cases"] == 40 and s["fused_ran"] == 36 and s["declined"] == 4            # SD3.5 qkv at 64 / 256 rows: cols % 256 != 0
+    assert s["cases"] == 48 and s["fused_ran"] == 44 and s["declined"] == 4            # FLUX mlp.2 at 1 / 4 rows, both dtypes
     assert s["fused_nondeterministic"] == 0
     assert s["worst_rms_ratio_fused_over_default"] <= 1.02, s
     assert s["worst_max_excess_in_output_ulps"] <= 1.0, s

@@ -116,6 +116,38 @@ def test_exact_arithmetic_cases_are_bit_equal(pkg, name, kind):
     assert torch.equal(pkg.fused.linear_mfma(x, w, tile_rows=256).cpu(), want), (name, kind, "shared-tile kernel")
 
 
+@pytest.mark.parametrize("name", ["Q4_0", "Q4_1", "Q5_0", "Q5_1", "Q8_0", "IQ4_NL"])
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_short_last_span_for_32_element_blocks(pkg, name, kind):
+    """Round 5: the contraction may end in a span shorter than 256 elements (a multiple of 64) for the 32-element legacy blocks -- SD3.5-large's
+    2432-column layers (Q5_0 in the Q4_K_M mix: lcpp.patch falls back when cols % 256 != 0).  One short span only (192), 1.25 spans (320: the short
+    one belongs to wave 1), 9.5 spans (2432: wave 1 again, after two full ones), 4.75 spans (1216: wave 0's second); every K-split tile shape;
+    tolerance against fp64 on the oracle's weights AND an exact-arithmetic case per shape (a dropped or doubled chunk of the tail cannot hide)."""
+    q = pkg.qtypes.Q[name]
+    dtype, eps = DT[kind]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(19)
+    for rows, cols, m, with_bias, tile in ((70, 192, 5, True, 0), (33, 320, 40, False, 0), (96, 2432, 31, True, 32), (64, 2432, 100, False, 64),
+                                           (40, 1216, 260, True, 128), (7296 // 8, 2432, 256, True, 0), (50, 448, 64, False, 0)):
+        blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
+        bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if with_bias else None
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None)
+        assert y.shape == (m, rows) and y.dtype == dtype
+        _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
+        assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None))
+        # exact arithmetic on the same shape: integer x, power-of-two scales -> the correctly rounded exact value, bit for bit
+        eb = _exact_blocks(pkg, q, rows, cols, seed=5)
+        ew = pkg.ops.GGMLTensor(torch.from_numpy(eb).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        w64 = _dense_weight(q, eb, kind, rows, cols)
+        xi = torch.randint(-4, 5, (m, cols), device=DEV, generator=g).to(dtype)
+        x64 = xi.double().cpu().numpy()
+        if (np.abs(x64) @ np.abs(w64).T).max() < 2.0 ** 16:
+            want = torch.from_numpy(x64 @ w64.T).to(dtype)
+            assert torch.equal(pkg.fused.linear_mfma(xi, ew, tile_rows=tile, auto_max_rows=None).cpu(), want), (name, kind, rows, cols, m, "exact")
+
+
 def test_mfma_linear_limits(pkg):
     Q, ops, GGQUnsupported = pkg.qtypes.Q, pkg.ops, pkg.dequant.GGQUnsupported
     mk = lambda q, shape, **kw: ops.GGMLTensor(torch.from_numpy(pkg.synth.make_tensor_bytes(q, shape, seed=1)).to(DEV), tensor_type=q, tensor_shape=shape, **kw)
@@ -126,7 +158,9 @@ def test_mfma_linear_limits(pkg):
     assert torch.equal(pkg.fused.linear_mfma(x.t().contiguous().t(), w), y.reshape(8, 64))   # non-contiguous x: handled by a copy
     for bad in (lambda: pkg.fused.linear_mfma(x.float(), w),                                  # fp32 activations
                 lambda: pkg.fused.linear_mfma(x, w, dequant_dtype=torch.float32),
-                lambda: pkg.fused.linear_mfma(x[:, :128], mk(Q.Q8_0, (64, 128))),             # cols % 256
+                lambda: pkg.fused.linear_mfma(x[:, :96], mk(Q.Q8_0, (64, 96))),               # 32-element blocks: the last span must be a multiple of 64
+                lambda: pkg.fused.linear_mfma(x[:, :384], mk(Q.Q8_0, (64, 384)), tile_rows=256),  # ... and the shared-tile kernel takes whole spans only
+                lambda: pkg.fused.linear_mfma(x, mk(Q.Q4_K, (64, 512)).as_subclass(torch.Tensor)),  # not a GGMLTensor: no tensor_type
                 lambda: pkg.fused.linear_mfma(x, mk(Q.Q4_K, (64, 512), patches=[("p", "k")])),
                 lambda: pkg.fused.linear_mfma(x.cpu(), w),
                 lambda: pkg.fused.linear_mfma(x, w, tile_rows=48),
