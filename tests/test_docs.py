@@ -18,7 +18,7 @@ def _tool():
 def test_every_numbers_block_is_what_the_measurement_files_say():
     T = _tool()
     blk = T.blocks()
-    want = {"DESIGN.md": {"headline-table", "fused-error"}, "INTEGRATION.md": {"summary", "token-sweep", "fused-error"}, "README.md": {"summary"}}
+    want = {"DESIGN.md": {"headline-table", "fused-error"}, "INTEGRATION.md": {"summary", "token-sweep", "token-sweep-sd35", "token-sweep-t5", "fused-error"}, "README.md": {"summary"}}
     for doc in T.DOCS:
         old = open(os.path.join(ROOT, doc)).read()
         new, found = T.apply(old, blk)

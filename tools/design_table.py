@@ -7,7 +7,7 @@ whose text this script derives from the committed measurement files and nothing 
 
     profiles/r05_bench_n1.json                              one `python bench.py` line (the newest profiles/r*_bench_n1.json unless given)
     profiles/pmc_traffic.json                               PMC bytes per launch
-    profiles/r05_flux_forward_emulation_token_sweep.json    tools/token_sweep.py
+    profiles/r05_flux_forward_emulation_token_sweep.json    tools/token_sweep.py (and r05_forward_emulation_token_sweep_sd35.json / _t5.json)
     profiles/r05_fused_error.json                           tools/fused_error.py
 
     python tools/design_table.py [bench.json]            # prints every block
@@ -163,9 +163,11 @@ def blocks(bench_path=None):
     d = load(bench_path)
     tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     out = {"headline-table": headline_table(d, tr, rel(bench_path)), "summary": summary(d, rel(bench_path))}
-    p = os.path.join(ROOT, "profiles", "r05_flux_forward_emulation_token_sweep.json")
-    if os.path.exists(p):
-        out["token-sweep"] = token_table(load(p), rel(p))
+    for name, fname in (("token-sweep", "r05_flux_forward_emulation_token_sweep.json"), ("token-sweep-sd35", "r05_forward_emulation_token_sweep_sd35.json"),
+                        ("token-sweep-t5", "r05_forward_emulation_token_sweep_t5.json")):
+        p = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(p):
+            out[name] = token_table(load(p), rel(p))
     p = os.path.join(ROOT, "profiles", "r05_fused_error.json")
     if os.path.exists(p):
         out["fused-error"] = fused_error_block(load(p), rel(p))
