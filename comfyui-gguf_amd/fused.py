@@ -121,6 +121,12 @@ AUTO_MAX_ROWS = 256      # rows of x up to which a fused MFMA shape beats dequan
                          # and profiles/r04_gemm_skeleton_sweep.json shows why that gap does not close: DESIGN.md section 4c)
 
 
+# ... and, above 128 rows of x, the product (rows of x) x (rows of the weight) beyond which the K-split kernel's repeated decode (once per 64 rows of x) costs more than
+# one unpack + hipBLASLt: FLUX's 21504 x 3072 `linear1` at 192 / 256 rows runs 79.6 / 78.3 us fused against 63.2 / 68.6 us unpack + F.linear, while 12288 x 3072 at 256 rows
+# (52.9 vs 54.6) and everything smaller still wins or is level (profiles/r05_mfma_tile_choice_96_to_256_rows.json).  21504 x 192 = 4.1 M declines, 12288 x 256 = 3.1 M stays.
+AUTO_MAX_ROWS_TIMES_OUT = 3_600_000
+
+
 def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None, auto_max_rows=AUTO_MAX_ROWS):
     """``F.linear(x, dequantize_tensor(weight, x.dtype), bias)`` on the matrix cores, from the packed blocks (include/ggq.h
     ``ggq_linear_mfma``).  x: (..., cols) fp16 / bf16 on the GPU; weight: GGMLTensor of logical shape (rows, cols) with
@@ -128,14 +134,16 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take.
 
     ``tile_rows=0`` (auto) never picks something slower than the default path: the library chooses the fastest fused shape for
-    (rows of x, rows of the weight), and inputs of more than ``auto_max_rows`` rows are DECLINED (GGQUnsupported: the caller keeps
+    (rows of x, rows of the weight), and inputs of more than ``auto_max_rows`` rows -- or of more than 128 rows on a weight so tall that
+    rows of x times rows of the weight exceeds ``AUTO_MAX_ROWS_TIMES_OUT`` -- are DECLINED (GGQUnsupported: the caller keeps
     dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
     kernel) or ``auto_max_rows=None`` forces the fused kernel at any size."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
     if tile_rows not in (0, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
         raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 32, 64, 128 or 256 (the shared-tile kernel: rows % 8 == 0, cols % 256 == 0)")
-    if tile_rows == 0 and auto_max_rows is not None and m > auto_max_rows:
-        raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x -- above {auto_max_rows} rows dequantize + F.linear is the faster path; pass tile_rows= to force a fused shape")
+    if tile_rows == 0 and auto_max_rows is not None and (m > auto_max_rows or (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)):
+        raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x on {rows} output columns -- dequantize + F.linear is the faster path there "
+                             f"(above {auto_max_rows} rows, or above 128 rows with rows x columns > {AUTO_MAX_ROWS_TIMES_OUT}); pass tile_rows= to force a fused shape")
     if _mfma_call is None:
         _bind()
     return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)

@@ -29,7 +29,9 @@ def test_fused_linears_are_no_further_from_fp64_than_unpack_plus_f_linear(pkg):
     assert len(pick) == 6
     out = T.measure(pkg, torch.device("cuda:0"), ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), shapes=pick)
     s = out["summary"]
-    assert s["cases"] == 48 and s["fused_ran"] == 44 and s["declined"] == 4            # FLUX mlp.2 at 1 / 4 rows, both dtypes
+    # declined: FLUX mlp.2 at 1 / 4 rows (row wider than the LDS staging) and the 18432-column-tall modulation weight at 256 rows (the auto policy hands tall weights
+    # back to unpack + F.linear above 128 rows: fused.AUTO_MAX_ROWS_TIMES_OUT), both dtypes
+    assert s["cases"] == 48 and s["fused_ran"] == 42 and s["declined"] == 6
     assert s["fused_nondeterministic"] == 0
     assert s["worst_rms_ratio_fused_over_default"] <= 1.02, s
     assert s["worst_max_excess_in_output_ulps"] <= 1.0, s

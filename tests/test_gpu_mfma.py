@@ -57,6 +57,9 @@ def test_auto_dispatch_reaches_the_shared_tile_kernel(pkg, name):
     x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
     with pytest.raises(pkg.dequant.GGQUnsupported):
         pkg.fused.linear_mfma(x, w)                                                         # 2304 rows of x: declined by default
+    with pytest.raises(pkg.dequant.GGQUnsupported):
+        pkg.fused.linear_mfma(x[:192], pkg.ops.GGMLTensor(torch.zeros(21504 * 256 // 256 * 144, dtype=torch.uint8, device=DEV), tensor_type=q, tensor_shape=(21504, 256))
+                              if name == "Q4_K" else w.as_subclass(torch.Tensor))          # 192 rows x 21504 output columns: the tall-weight rule (Q4_K leg)
     auto = pkg.fused.linear_mfma(x, w, auto_max_rows=None)
     tile, ksplit = pkg.fused.linear_mfma(x, w, tile_rows=256), pkg.fused.linear_mfma(x, w, tile_rows=128)
     _check(auto, x, _dense_weight(q, blocks, "bf16", rows, cols), None, DT["bf16"][1], cols)

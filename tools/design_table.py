@@ -151,7 +151,9 @@ def fused_error_block(fe, src):
     return "\n".join([
         f"Source: `{src}` (`tools/fused_error.py`, {fe.get('device', 'MI355X')}, torch {fe.get('torch', '?')}): {s['cases']} cases = every distinct linear shape of FLUX.1-dev / SD3.5-large / T5-xxl × "
         f"{{1, 4, 64, 256}} rows × {{bf16, fp16}}, error against an fp64 product on the ORACLE's weights, relative to RMS(exact).",
-        f"- fused kernel ran in {s['fused_ran']} cases (the other {s['declined']} it declines — rows wider than `ggq_linear_small`'s LDS staging at ≤ 4 rows: FLUX's 12288- and 15360-column layers, which never see so few rows — and they keep unpack + `F.linear`);",
+        f"- fused kernel ran in {s['fused_ran']} cases; the other {s['declined']} are declined and keep unpack + `F.linear`: rows wider than `ggq_linear_small`'s LDS staging at ≤ 4 rows (FLUX's 12288- and "
+        f"15360-column layers, which never see so few rows), and 256 rows of x on the tallest weights (≥ 14592 output columns), which the auto policy hands back because unpack + hipBLASLt is faster there "
+        f"(`fused.AUTO_MAX_ROWS_TIMES_OUT`);",
         f"- worst RMS-error ratio fused ÷ default: **{s['worst_rms_ratio_fused_over_default']:.7f}**; worst max-error ratio: **{s['worst_max_ratio_fused_over_default']:.4f}**; "
         f"max error never above the default path's by more than {max(0.0, s['worst_max_excess_in_output_ulps']):.2f} output rounding steps;",
         f"- outputs bit-identical to the default path's: ≥ {100 * s['min_same_bits_share']:.2f} % in every case; run-to-run: fused non-deterministic in {s['fused_nondeterministic']} cases, default in {s['default_nondeterministic']};",
