@@ -7,9 +7,12 @@ replaces ``dequantize`` and ``dequantize_tensor`` (reference dequant.py:15,30) -
 ``ops.py`` imported at load time (reference ops.py:9) -- by wrappers that send GPU-resident
 requests (any dequant_dtype the nodes offer) to the HIP kernels and hand EVERYTHING ELSE to the
 reference's own original functions: CPU tensors at load time (loader.py:124,253,...), qtypes
-without a kernel.  Nothing above ``dequantize_tensor`` changes:
+without a kernel.  With ``exact=True`` (``GGQ_EXACT=1``) nothing above ``dequantize_tensor`` changes:
 ``GGMLTensor``, ``GGMLOps``, the loader and the nodes keep running the reference's code, so the
-"Unet Loader (GGUF)" node works unchanged.  ``uninstall()`` restores the originals.
+"Unet Loader (GGUF)" node works unchanged and every output is bit-equal to the reference's own on the same GPU.
+The DEFAULT (``ref_ops`` given, no ``exact``) additionally turns on ``fast`` = ``fused_small_m`` + ``fused_mfma`` +
+``gather_embedding`` below (``DEFAULT_FAST``: measured no further from an fp64 product than F.linear, profiles/r05_fused_error.json).
+``uninstall()`` restores the originals.
 
 ``dense_cache_gb`` (or the environment variable ``GGQ_DENSE_CACHE_GB``) additionally keeps dequantized weights resident
 in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM for the per-step dequant work).
@@ -17,26 +20,26 @@ in HBM up to that budget (resident.py: opt-in, off by default -- it trades VRAM 
 ``fused_small_m`` (or ``GGQ_FUSED_SMALL_M=1``; needs ``ref_ops``) wraps ``GGMLOps.Linear.forward_ggml_cast_weights``
 (reference ops.py:242-244): inputs of one to four rows (FLUX's modulation layers) go through the fused dequantize +
 linear kernel (fused.py) when weight and input qualify, everything else -- LoRA-patched weights included -- through the
-reference's method.  Opt-in because the result matches F.linear up to fp32 summation order, not bit for bit.
+reference's method.  The result matches F.linear up to fp32 summation order, not bit for bit (same weights bit for bit): part of the default since round 5, off under ``exact``.
 
 ``fused_mfma`` (or ``GGQ_FUSED_MFMA=1``; needs ``ref_ops``) wraps the same method for inputs of up to ``fused_mfma_max_m`` rows
 (default 256, ``GGQ_FUSED_MFMA_MAX_M``): fused dequantize + GEMM on the matrix cores (fused.linear_mfma), 1.2-3x faster than
-dequantize + hipBLASLt in that range on FLUX / T5 layer shapes; above it hipBLASLt on the dense weight wins and keeps the job.
-Same opt-in reasoning: fp32 summation order.
+dequantize + hipBLASLt in that range on FLUX / T5 layer shapes; above it -- and above 128 rows on the tallest weights (fused.AUTO_MAX_ROWS_TIMES_OUT) -- hipBLASLt on
+the dense weight wins and keeps the job.  Same numerics statement; part of the default, off under ``exact``.
 
 ``gather_embedding`` (or ``GGQ_GATHER_EMBEDDING=1``; needs ``ref_ops``) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights``
 (reference ops.py:251-260): instead of dequantizing the whole table and then gathering, only the rows the token ids name are
 unpacked (dequant.dequantize_rows) -- bit-identical values, no transient dense table (a 152 k x 3584 vocabulary is 1.1 GB).
 Tables the kernel does not take (CPU, F16 / F32 storage, ``max_norm`` set, LoRA patches) keep the
-reference's method.
+reference's method.  Ids outside the table fail as F.embedding's do (asynchronous device-side assert; ``GGQ_CHECK_INDICES=0``: the kernel's clamp).  Part of the default.
 
 ``cpu_route_mb`` (or ``GGQ_CPU_ROUTE_MB=N``): CPU-resident quantized tensors of at least N MB of packed bytes -- the load-time
 callers, token_embd / mmproj tables (reference loader.py:253-254,270,386,397) -- are uploaded, unpacked on the GPU and copied back
 (dequant.dequantize_tensor_via_gpu) instead of running the reference's torch-CPU ops: same bits, CPU result.  Off by default (it
 touches the GPU at load time, before ComfyUI's model management has placed anything).
 
-``fast`` (or ``GGQ_FAST=1``): ``fused_small_m`` + ``fused_mfma`` + ``gather_embedding`` in one switch -- the opt-ins that hold no VRAM and measured faster
-wherever they apply.
+``fast`` (or ``GGQ_FAST=1``): ``fused_small_m`` + ``fused_mfma`` + ``gather_embedding`` in one switch -- the options that hold no VRAM and measured faster
+wherever they apply.  The default when ``ref_ops`` is given; ``exact`` (``GGQ_EXACT=1``) is its opposite.
 
 ``overlap`` (or ``GGQ_OVERLAP=1``; needs ``ref_ops``) wraps ``GGMLLayer.cast_bias_weight`` (reference ops.py:194-211) with
 overlap.LayerPrefetcher: for CPU-resident packed weights (low-VRAM mode, ops.py:209) the NEXT layer's bytes are copied host->device
