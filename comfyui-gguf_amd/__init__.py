@@ -12,7 +12,7 @@ fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
     gguf_file   GGUF container reader (native parser) + file -> HBM streaming upload
     loader      gguf_sd_loader & co. (reference loader.py:16-141) without the `gguf` package
     resident    opt-in cache that keeps dequantized weights resident in HBM (288 GB make it possible)
-    fused       opt-in fused dequantize + linear for inputs of one to four rows (modulation layers)
+    fused       fused dequantize + linear: 1-4 rows (modulation layers) and, on the matrix cores, up to 256 rows; install()'s default
     overlap     opt-in side-stream prefetch: layer i+1's (host->device copy and) unpack under layer i's GEMM
     sharding    tensor-list partitioning for one-process-per-GPU runs (no collectives)
     ops         GGMLTensor / GGMLLinear stand-ins for driving the path without ComfyUI

@@ -13,7 +13,8 @@
 // activations, separate fp32 multiplies and adds for fp32 ones), chunk by chunk per lane, and reduces the 64 lanes by a butterfly:
 // like any GEMV, the result differs from rocBLAS's by the order of fp32 additions only.  Parity is therefore stated
 // against an fp32 reference of the same op with a tolerance (tests/test_gpu_linear.py), not bit for bit -- which is why
-// this path is OPT-IN and the drop-in default stays dequantize + F.linear.
+// install(exact=True) keeps dequantize + F.linear; the default install uses this path since round 5, after tools/fused_error.py measured it no further from an fp64
+// product than F.linear on every FLUX / SD3.5 / T5 layer shape (profiles/r05_fused_error.json).
 //
 // Shape of the work: one WAVE per output row, rows dealt round-robin to a persistent grid.  x (m x cols, 16- or 32-bit)
 // is staged once per workgroup in LDS; per row the wave copies the row's packed bytes (cols/block_size * type_size, e.g.

@@ -26,7 +26,7 @@
 // Numerics: the WEIGHTS are the reference's values bit for bit (same decode, same fp16 op sequence, then the `.to(dtype)` of
 // dequantize_tensor); products are exact in fp32, accumulation is fp32 in the MFMA's order.  Like any GEMM against another GEMM the
 // result differs from hipBLASLt's by summation order: parity is a tolerance against an fp64 evaluation on the oracle's weights
-// (tests/test_gpu_mfma.py), hence OPT-IN.
+// (tests/test_gpu_mfma.py); part of install()'s default for up to 256 rows of x since round 5 (profiles/r05_fused_error.json), off under `exact`.
 #pragma once
 
 #include "ggq_linear.hpp"

@@ -1,4 +1,4 @@
-"""Opt-in: ``F.linear`` on a quantized weight straight from the packed blocks -- the dense weight is never written.
+"""``F.linear`` on a quantized weight straight from the packed blocks -- the dense weight is never written.  (Part of install()'s default since round 5.)
 Two kernels: ``linear_small`` for ONE TO FOUR rows of input (include/ggq.h ``ggq_linear_small``, csrc/ggq_linear.hpp: HBM-bound,
 no matrix cores) and ``linear_mfma`` for many rows (``ggq_linear_mfma``, csrc/ggq_mfma.hpp: each lane decodes the eight
 consecutive weights that are its MFMA operand).
@@ -9,7 +9,8 @@ The reference's ``GGMLOps.Linear.forward_ggml_cast_weights`` (ops.py:242-244) de
 
 The weights are the reference's values bit for bit (same decode, same fp16 op sequence, same ``.to(dtype)``); the dot products
 accumulate in fp32 in this kernel's own order, so the result equals ``F.linear(x, dequantize_tensor(w, x.dtype), bias)`` up to
-fp32 summation order -- parity is a tolerance against an fp32 reference (tests/test_gpu_linear.py), not bit-exact, hence opt-in:
+fp32 summation order -- parity is a tolerance against an fp32 reference (tests/test_gpu_linear.py), not bit-exact; measured against an fp64 product the fused
+results are no further from exact than F.linear's (tools/fused_error.py, profiles/r05_fused_error.json), which is why install() turns them on by default (``exact=True`` off):
 ``GGMLLinear.fuse_small_m = True`` for the stand-in, ``install(..., fused_small_m=True)`` for a ComfyUI-GGUF checkout.
 """
 import torch

@@ -98,7 +98,7 @@ class GGMLLayer(torch.nn.Module):
 
 
 class GGMLLinear(GGMLLayer):
-    """``GGMLOps.Linear`` (ops.py:227-244).  ``fuse_small_m`` / ``fuse_mfma_max_m`` (opt-in, fused.py): inputs of at most four rows /
+    """``GGMLOps.Linear`` (ops.py:227-244).  ``fuse_small_m`` / ``fuse_mfma_max_m`` (off in this stand-in; install()'s default over the reference's class, fused.py): inputs of at most four rows /
     of at most that many rows go through a fused dequantize + linear kernel instead of dequantize-then-F.linear."""
 
     fuse_small_m = False

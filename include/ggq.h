@@ -172,7 +172,7 @@ int ggq_overlap_prefetch(ggq_overlap* ov, int slot, int staging_slot, int qtype,
 int ggq_overlap_wait(ggq_overlap* ov, int slot, void* main_stream);
 void ggq_overlap_destroy(ggq_overlap* ov);
 
-/* ---- fused dequantize + linear for a few rows of x (opt-in) ------------------------- */
+/* ---- fused dequantize + linear for a few rows of x -------------------------------------- */
 
 /* y[m, rows] = x[m, cols] @ W^T (+ bias[rows]), W = dequantize_tensor(packed, dtype) of logical shape (rows, cols), 1 <= m <= 4,
  * computed straight from the packed blocks: the dense weight is never written.  x, bias, y are of `dtype` (ggq_dtype) and
