@@ -1,6 +1,7 @@
 // ggq_linear.hip -- C ABI over ggq_linear.hpp: y = x @ dequant(W)^T + bias for m <= 4 rows of x, from the packed blocks.
 #include "ggq_linear.hpp"
 #include "ggq_mfma.hpp"
+#include "ggq_mfma16.hpp"
 #include "ggq_gemm.hpp"
 #include "ggq_host.hpp"
 #include "../../include/ggq.h"
@@ -103,6 +104,39 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
     return hipGetLastError();
 }
 
+// ---- the 16-row MFMA kernel (ggq_mfma16.hpp): tile = MB*16 rows of x  x  16 output columns, K split over KW waves of the workgroup.
+// KW: enough waves that every SIMD holds several (one wave's memory wait is another's issue slot), never more than the 256-element spans of a row,
+// and -- among the candidates -- the one whose slowest wave has the fewest spans; ties go to the smaller workgroup (less to sum at the end).
+uint32_t mf16_waves(uint32_t tiles, uint32_t n_spans, uint32_t cus, uint32_t min_kw)
+{
+    static const int lab_kw = lab_int("GGQ_MF16_KW", 1, MF16_MAX_WAVES);             // lab builds only, read once (-1 in the shipped library)
+    const uint32_t cap = n_spans < (uint32_t)MF16_MAX_WAVES ? n_spans : (uint32_t)MF16_MAX_WAVES;
+    if (lab_kw >= 1) return (uint32_t)lab_kw < min_kw ? min_kw : ((uint32_t)lab_kw > cap && cap >= min_kw ? cap : (uint32_t)lab_kw);
+    static const int lab_wps = lab_int("GGQ_MF16_WPS", 1, 8);
+    const uint32_t slots = cus * 4u * (lab_wps >= 1 ? (uint32_t)lab_wps : 6u);       // waves the chip holds at the kernels' register count
+    uint32_t best = min_kw, best_cost = ~0u;
+    for (uint32_t kw = min_kw; kw <= (cap > min_kw ? cap : min_kw); kw++) {
+        const uint32_t per_wave = (n_spans + kw - 1) / kw, rounds = (tiles * kw + slots - 1) / slots;
+        // a wave's life ~ one memory latency + its spans; a second round of workgroups costs another whole life
+        const uint32_t cost = rounds * (2u + per_wave);
+        if (cost < best_cost) { best_cost = cost; best = kw; }
+    }
+    return best;
+}
+
+template <class F, int OUT, int MB, bool XC, int NT>
+hipError_t launch_mfma16(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+{
+    const dim3 grid((rows + (uint32_t)(NT * 16) - 1u) / (uint32_t)(NT * 16), (m + (uint32_t)(MB * 16) - 1u) / (uint32_t)(MB * 16));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t kw = mf16_waves(grid.x * grid.y, (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN, compute_units(dev), 2u);
+    const uint32_t lds = mf16_lds_bytes<F, MB, NT>(kw);
+    hipLaunchKernelGGL((linear_mfma16<F, OUT, MB, XC, NT>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed),
+                       static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
+    return hipGetLastError();
+}
+
 // ---- the shared-tile kernel (ggq_gemm.hpp): 256 rows of x  x  256 output columns per workgroup, weights decoded once per workgroup.
 // WM = 4 (shipped): 16 waves, 64 x 64 outputs each, 4 waves per SIMD; WM = 2: 8 waves, 128 x 64 each, 2 waves per SIMD -- 2-6 % slower
 // (profiles/r03_gemm_tile_16_waves_and_xring.json), compiled only into A/B builds (-DGGQ_TILE_WM_AB; GGQ_TILE_WM=2 in the environment then picks it).
@@ -136,9 +170,10 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
     return launch_tile_wm<F, OUT, GGQ_TILE_WM_DEFAULT>(packed, x, bias, y, m, rows, cols, s);
 }
 
-constexpr int MFMA_SHAPES = 4;                   // MB = 1, 2, 4 (K-split kernel), then the 256 x 256 shared-tile kernel
+constexpr int MFMA_SHAPES = 12;                   // MB = 1, 2, 4 (K-split kernel), the 256 x 256 shared-tile kernel, then the 16-row kernel with one / two blocks of x
 struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][shape]
-#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>}
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>, launch_mfma16<F, OUT, 1, false, 1>, launch_mfma16<F, OUT, 2, false, 1>, launch_mfma16<F, OUT, 1, true, 1>, launch_mfma16<F, OUT, 2, true, 1>, \
+                            launch_mfma16<F, OUT, 1, false, 2>, launch_mfma16<F, OUT, 2, false, 2>, launch_mfma16<F, OUT, 1, true, 2>, launch_mfma16<F, OUT, 2, true, 2>}
 #define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
@@ -182,6 +217,9 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
         const bool tile_ok = !k_tail && m >= tile_min_m() && rows % 8u == 0 && rows <= (1u << 22) && aligned16(y) && n_tiles >= 80u;
         shape = m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2));
     }
+    // the 16-row kernel (ggq_mfma16.hpp): one block of 16 rows of x per tile up to m = 16, else two.  16 = its sub-block-per-lane k map, 17 = its x-contiguous map,
+    // 18 / 19 = the same two with TWO 16-row blocks of W per wave (32 output columns per workgroup)
+    else if (tile_rows >= 16 && tile_rows <= 19) shape = (m <= 16 ? 4 : 5) + ((tile_rows & 1) ? 2 : 0) + (tile_rows >= 18 ? 4 : 0);
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
     if (shape == 3 && (k_tail || rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;   // whole spans only; 16-byte pieces of y; 32-bit offsets inside a tile's rows of y

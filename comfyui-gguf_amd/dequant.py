@@ -390,6 +390,46 @@ def dequantize_rows(tensor, indices, dtype=None, dequant_dtype=None, check_indic
     return out
 
 
+# ---- torch.compile: the row lookup as an opaque custom op (the Embedding wrapper of install(); same reasons as ggq::dequantize above)
+def _dequantize_rows_op_impl(packed: torch.Tensor, indices: torch.Tensor, qtype: int, n_rows: int, cols: int, compute: int, out: int, check: bool) -> torch.Tensor:
+    from .ops import GGMLTensor
+    table = GGMLTensor(packed, tensor_type=Q(qtype), tensor_shape=(n_rows, cols))
+    cd = {v: k for k, v in _COMPUTE_CODE.items() if k is not None}[compute]
+    return dequantize_rows(table, indices, _TORCH_OF_CODE[out], cd, check_indices=check)
+
+
+def _dequantize_rows_op_fake(packed, indices, qtype, n_rows, cols, compute, out, check):
+    return packed.new_empty(tuple(indices.shape) + (cols,), dtype=_TORCH_OF_CODE[out])
+
+
+try:
+    _dequantize_rows_op = torch.library.custom_op("ggq::dequantize_rows", _dequantize_rows_op_impl, mutates_args=(), device_types="cuda")
+    _dequantize_rows_op.register_fake(_dequantize_rows_op_fake)
+except (AttributeError, RuntimeError):
+    _dequantize_rows_op = None
+
+
+def dequantize_rows_traced(tensor, indices, dtype, dequant_dtype, check_indices):
+    """``dequantize_rows`` while torch.compile traces install()'s Embedding wrapper: the custom op, or None when the eager call would have raised
+    GGQUnsupported (the caller then traces the reference's method).  Conditions on trace-time constants only."""
+    if _dequantize_rows_op is None:
+        return None
+    key = _qtype_key(getattr(tensor, "tensor_type", None))
+    shape = tuple(getattr(tensor, "tensor_shape", ()))
+    cd = dtype if dequant_dtype == "target" else dequant_dtype
+    if key not in _HIP_TABLE or len(shape) != 2 or cd not in _COMPUTE_CODE:
+        return None
+    out_dtype = _COMPUTE_TORCH[cd] if dtype is None else dtype
+    qid, block_size, type_size = _HIP_TABLE[key]
+    n_rows, cols = int(shape[0]), int(shape[1])
+    if out_dtype not in _OUT_CODE or cols % block_size or not tensor.is_cuda or not indices.is_cuda or indices.dtype not in (torch.int64, torch.int32):
+        return None
+    packed = _as_bytes(tensor, align=False)
+    if packed.numel() != n_rows * (cols // block_size) * type_size:
+        return None
+    return _dequantize_rows_op(packed, indices, qid, n_rows, cols, _COMPUTE_CODE[cd], _OUT_CODE[out_dtype], bool(check_indices))
+
+
 # ---- dequantize_functions: the reference's per-format block functions (dequant.py:287-301) --------
 
 def dequantize_blocks_BF16(blocks, block_size, type_size, dtype=None):

@@ -252,16 +252,20 @@ def _account_scratch(layer_cls, rec):
 
 def _gather_embedding(embedding_cls, unsupported):
     """Wrap ``embedding_cls.forward_ggml_cast_weights``; returns the (owner, name, original) record uninstall() restores."""
-    from .dequant import _check_indices_default, dequantize_rows
+    from .dequant import _check_indices_default, dequantize_rows, dequantize_rows_traced
     reference_forward = embedding_cls.forward_ggml_cast_weights
     check = _check_indices_default(True)           # the reference's F.embedding fails on an id outside the table: so does the drop-in (GGQ_CHECK_INDICES=0: clamp)
+    is_compiling = _hip._is_compiling
 
     def forward_ggml_cast_weights(self, input, out_dtype=None):
         weight = self.weight
-        if (not _hip._is_compiling() and input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
+        if (input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
                 and not getattr(weight, "patches", None)):
             # the table's dtype the reference's way: out_dtype, else what cast_bias_weight(self, ...) falls back to (ops.py:196-197)
             table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
+            if is_compiling():                     # torch.compile: the same kernel as the custom op ggq::dequantize_rows (None: the reference's method)
+                rows = dequantize_rows_traced(weight.to(input.device), input, table_dtype, self.dequant_dtype, check)
+                return rows.to(dtype=out_dtype) if rows is not None else reference_forward(self, input, out_dtype)
             try:
                 return dequantize_rows(weight.to(input.device), input, table_dtype, self.dequant_dtype, check_indices=check).to(dtype=out_dtype)
             except unsupported:
@@ -277,14 +281,18 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
     """Wrap ``linear_cls.forward_ggml_cast_weights``: inputs of 1..4 rows -> fused.linear_small (when ``small_m``), inputs of up
     to ``mfma_max_m`` rows -> fused.linear_mfma; everything else, and everything either kernel declines, -> the reference's method.
     Returns the (owner, name, original) record uninstall() restores."""
-    from .fused import MAX_ROWS, linear_mfma, linear_small
+    from .fused import MAX_ROWS, linear_mfma, linear_small, linear_traced
     reference_forward = linear_cls.forward_ggml_cast_weights
+    is_compiling = _hip._is_compiling
 
     def forward_ggml_cast_weights(self, input):
         weight = self.weight
-        # torch.compile traces the REFERENCE's method only (its unpack is the opaque custom op ggq::dequantize, dequant.py): a fused kernel behind a
-        # ctypes call is nothing Dynamo can put in a graph, and a graph break per layer would cost more than the fusion saves
-        if weight is not None and input.is_cuda and not _hip._is_compiling():
+        if is_compiling():
+            # torch.compile (the reference allows full compile on torch >= 2.8, ops.py:11-42): a ctypes call is nothing Dynamo can put in a graph, so the
+            # SAME kernels go in as the custom ops ggq::linear_small / ggq::linear_mfma (fused.linear_traced); None = this call is the reference's
+            y = linear_traced(self, input, small_m, mfma_max_m)
+            return y if y is not None else reference_forward(self, input)
+        if weight is not None and input.is_cuda:
             cols = input.shape[-1]
             m = input.numel() // cols if cols else 0
             try:

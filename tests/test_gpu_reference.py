@@ -360,22 +360,91 @@ def test_module_to_device_then_forward(mods, pkg, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("options", [{}, {"fast": True}], ids=["exact", "round-5-default"])
-def test_torch_compile_through_reference_linear(mods, pkg, dev, options):
-    """The reference allows full compile on torch >= 2.8 (ops.py:20-42): Dynamo traces through its forward into our custom op.  With the round-5
-    default (fused linears on) the compiled function still traces the REFERENCE's method -- the wrappers stand aside while compiling -- so the
-    compiled result is the exact path's, bit for bit, also for an input small enough for the fused kernels."""
+@pytest.mark.parametrize("m", [2, 8, 64])
+def test_torch_compile_through_reference_linear(mods, pkg, dev, options, m):
+    """The reference allows full compile on torch >= 2.8 (ops.py:20-42): Dynamo traces through its forward into our custom ops.  Under ``exact`` that is
+    ``ggq::dequantize`` + F.linear; under the default (fused linears on) the wrapper routes to ``ggq::linear_small`` (m <= 4) / ``ggq::linear_mfma``
+    (round 6: until then the wrappers stood aside and a compiled model silently got the exact path).  Either way the compiled function must return
+    what the EAGER run of the same installation returns, bit for bit -- same kernels, deterministic -- and the trace must not break the graph."""
     ro, Q = mods["ops"], pkg.qtypes.Q
     lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=41)
-    x = torch.randn(8 if not options else 2, 512, device=dev, dtype=torch.float16)
-    with H.Installed(pkg, mods):
-        want = lin(x)
+    x = torch.randn(m, 512, device=dev, dtype=torch.float16)
     with H.Installed(pkg, mods, **options):
+        want = lin(x)
         try:
-            fn = torch.compile(lambda t: lin(t), backend="eager")
+            torch._dynamo.reset()
+            explained = torch._dynamo.explain(lambda t: lin(t))(x)
+            fn = torch.compile(lambda t: lin(t), backend="eager", fullgraph=True)
             got = fn(x)
         except Exception as e:                                  # noqa: BLE001 -- Dynamo's support for this subclass is the reference's business
-            pytest.skip(f"torch.compile cannot trace the reference's GGMLTensor on this torch: {type(e).__name__}")
+            pytest.skip(f"torch.compile cannot trace the reference's GGMLTensor on this torch: {type(e).__name__}: {str(e)[:200]}")
+        finally:
+            torch._dynamo.reset()
+    assert explained.graph_break_count == 0, explained.break_reasons
     assert torch.equal(got, want)
+    if options:
+        # the default really went through a fused op (not through unpack + F.linear, whose bits differ in the last place somewhere in 32 x m outputs ...
+        ops_seen = {str(n.target) for g in explained.graphs for n in g.graph.nodes if n.op == "call_function"}
+        assert any("ggq.linear_small" in o for o in ops_seen) if m <= 4 else any("ggq.linear_mfma" in o for o in ops_seen), ops_seen
+    else:
+        ops_seen = {str(n.target) for g in explained.graphs for n in g.graph.nodes if n.op == "call_function"}
+        assert any("ggq.dequantize" in o for o in ops_seen) and not any("ggq.linear" in o for o in ops_seen), ops_seen
+
+
+def test_torch_compile_default_embedding_and_declined_layers(mods, pkg, dev):
+    """Under the default install a compiled Embedding goes through ``ggq::dequantize_rows``; a layer the fused kernels decline while tracing (here: a
+    LoRA-patched weight, 300 rows of x) traces the reference's method -- same results as eager, no graph break."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    emb, _ = H.make_embedding(ro, pkg, Q.Q6_K, 64, 512, dev, seed=5)
+    ids = torch.tensor([[0, 63, 7, 7, 12]], device=dev)
+    lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=42, patches=H.lora_patch((32, 512), 7))
+    big, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=43)
+    x = torch.randn(4, 512, device=dev, dtype=torch.float16)
+    x300 = torch.randn(300, 512, device=dev, dtype=torch.float16)
+    with H.Installed(pkg, mods, fast=True):
+        want = (emb(ids, out_dtype=torch.float16), lin(x), big(x300))
+        try:
+            torch._dynamo.reset()
+            ex = torch._dynamo.explain(lambda i, a, b: (emb(i, out_dtype=torch.float16), lin(a), big(b)))(ids, x, x300)
+            got = torch.compile(lambda i, a, b: (emb(i, out_dtype=torch.float16), lin(a), big(b)), backend="eager")(ids, x, x300)
+        except Exception as e:                                  # noqa: BLE001
+            pytest.skip(f"torch.compile cannot trace the reference's classes on this torch: {type(e).__name__}: {str(e)[:200]}")
+        finally:
+            torch._dynamo.reset()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    ops_seen = {str(n.target) for g in ex.graphs for n in g.graph.nodes if n.op == "call_function"}
+    assert any("ggq.dequantize_rows" in o for o in ops_seen), ops_seen
+    assert not any("ggq.linear" in o for o in ops_seen), ops_seen            # both linears were the reference's: LoRA patches / too many rows
+
+
+def test_autograd_through_the_default_install(mods, pkg, dev):
+    """the fused kernels return a tensor with no grad_fn.  When autograd is recording and the input (or the bias) wants a gradient --
+    a LoRA-training node, gradient-based guidance -- the default install must hand the call to the reference's dequantize + F.linear, so that
+    ``x.grad`` is what the exact installation produces; under no_grad (ComfyUI's sampling) the same layer still runs fused."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 32, 512, dev, seed=44)
+    for m in (2, 40):
+        x = torch.randn(m, 512, device=dev, dtype=torch.float16)
+        out = {}
+        for name, options in (("exact", {}), ("default", {"fast": True})):
+            xi = x.clone().requires_grad_()
+            with H.Installed(pkg, mods, **options):
+                y = lin(xi)
+                assert y.requires_grad and y.grad_fn is not None, (name, m)
+                y.float().square().sum().backward()                      # d/dx sum(y^2) = 2 y W: needs the graph through F.linear
+            out[name] = xi.grad
+        assert torch.equal(out["exact"], out["default"]), m
+    with H.Installed(pkg, mods, fast=True), torch.no_grad():
+        x = torch.randn(2, 512, device=dev, dtype=torch.float16)
+        calls = []
+        real = pkg.fused._small_call or (pkg.fused._bind() or pkg.fused._small_call)
+        pkg.fused._small_call = lambda *a: (calls.append(1), real(*a))[1]
+        try:
+            lin(x)
+        finally:
+            pkg.fused._small_call = real
+        assert calls, "under no_grad the default install still runs the fused kernel"
 
 
 def test_torch_compile_inductor_through_reference_linear(mods, pkg, dev):
@@ -405,6 +474,27 @@ def test_torch_compile_inductor_through_reference_linear(mods, pkg, dev):
     assert torch.equal(got_w.as_subclass(torch.Tensor).view(torch.int16), want_w.as_subclass(torch.Tensor).view(torch.int16))
     assert H.same_bits(want_w, H.oracle_tensor(Q.Q4_K, packed, torch.bfloat16, None, (64, 512)))
     assert torch.allclose(got.float(), want.float(), rtol=2.0 ** -6, atol=2.0 ** -6 * float(want.float().abs().max()))
+
+
+@pytest.mark.parametrize("m", [2, 64])
+def test_torch_compile_inductor_keeps_the_default_fused_kernels(mods, pkg, dev, m):
+    """Round 6: the default backend (inductor) over the DEFAULT install.  The layer is one opaque custom op (``ggq::linear_small`` at 2 rows,
+    ``ggq::linear_mfma`` at 64) inside inductor's graph -- here with a pointwise op behind it so that inductor has something to generate -- and
+    the result equals the eager default's, bit for bit, twice."""
+    ro, Q = mods["ops"], pkg.qtypes.Q
+    lin, _ = H.make_linear(ro, pkg, Q.Q4_K, 64, 512, dev, seed=47)
+    x = torch.randn(m, 512, device=dev, dtype=torch.bfloat16)
+    with H.Installed(pkg, mods, fast=True):
+        want = lin(x) * 2
+        try:
+            torch._dynamo.reset()
+            fn = torch.compile(lambda t: lin(t) * 2)
+            got, again = fn(x), fn(x)
+        except Exception as e:                                                      # noqa: BLE001 -- no compiler / no triton backend on this box
+            pytest.skip(f"inductor cannot compile here: {type(e).__name__}: {str(e)[:300]}")
+        finally:
+            torch._dynamo.reset()
+    assert torch.equal(got, want) and torch.equal(again, want)
 
 
 def test_cpu_route_for_load_time_tensors(mods, pkg, dev, monkeypatch):
