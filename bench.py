@@ -31,6 +31,8 @@ Other workloads (not the driver's default; same JSON contract, one line):
   --workload sd35-t5     BASELINE configs[4]: SD3.5-large + T5-xxl weight tensors (549 tensors), same treatment.
   --workload flux-gguf   the FLUX weight set written to a synthetic .gguf file, then parsed by the native
                          reader, streamed file -> pinned -> HBM and dequantized: the PCIe-inclusive rate.
+  --workload fused       the fused dequantize + linear kernels of install()'s default on the FLUX set at 1 / 4 / 32 / 64 / 256 rows of x, graph-replayed, with their
+                         packed-read roofline (also sub-lines `fused_small_m` / `fused_mfma` of the default run).
   --workload fused-error the numerics table behind install()'s default (tools/fused_error.py): fused linears vs unpack + F.linear against fp64; not a throughput line.
   --workload per-layer   the FLUX weight set the way the node drives it (ops.py:177): one dequantize_tensor() launch per tensor, bf16
                          result -- standalone (graph-replayed, both store policies), eager, in context (unpack + F.linear per layer vs
@@ -963,6 +965,104 @@ def run_per_layer(pkg, args, device, fence):
     return line
 
 
+def run_fused(pkg, args, device):
+    """The fused dequantize + linear kernels that ARE install()'s default for small inputs (reference ops.py:242-244, GGMLOps.Linear.forward_ggml_cast_weights),
+    under the same clock as everything else: every quantized linear of the FLUX.1-dev set (304 layers, Q4_K_M mix, 6.79 GB packed -- 26x the Infinity
+    Cache, so a pass streams every weight from HBM) called through the default policy (fused.linear_auto) with m rows of bf16 input, one pass =
+    304 launches replayed from a captured HIP graph, HIP events around `passes` replays, median of `regions`.
+      fused_small_m: m = 1, 4     fused_mfma: m = 32, 64, 256
+    roofline: bound "hbm", achieved = PACKED bytes of the layers the fused path took / time -- these kernels read the packed weight once and write m x rows
+    outputs, so the packed read is the algorithmic traffic; TFLOP/s beside it.  Layers the policy declines at that m (the auto
+    rule hands tall weights above 128 rows to unpack + hipBLASLt) are listed and left out of both the bytes and the time.  Parity (outside the timed
+    regions): three layers per m against an fp64 product on the ORACLE's weights, fp32-accumulation bound."""
+    import numpy as np
+    import oracle
+    manifest = pkg.manifests.flux_dev(args.mix)
+    if args.limit_tensors:
+        manifest = manifest[:args.limit_tensors]
+    dtype = torch.bfloat16
+    tensors = []
+    for i, (_, q, shape) in enumerate(manifest):
+        n_blocks = pkg.synth.n_blocks_for(q, shape[0] * shape[1])
+        tensors.append(pkg.ops.GGMLTensor(device_blocks(pkg, q, n_blocks, device, 7000 + i), tensor_type=q, tensor_shape=shape))
+    packed_of = [t.as_subclass(torch.Tensor).numel() for t in tensors]
+    passes = max(3, args.steps // 10)
+    stream = torch.cuda.current_stream(device)
+    unsupported = pkg.dequant.GGQUnsupported
+    sample = sorted({(q, shape): i for i, (_, q, shape) in reversed(list(enumerate(manifest)))}.items(), key=lambda kv: kv[0][1][0] * kv[0][1][1])[:3]
+    sample = [i for _, i in sample]                                       # the three smallest distinct (format, shape) layers: the CPU side stays in seconds
+    dense64 = {}
+
+    def check(i, x, y):
+        _, q, (rows, cols) = manifest[i]
+        if i not in dense64:
+            raw = tensors[i].as_subclass(torch.Tensor).cpu().numpy()
+            w = oracle.dequant_tensor(q, raw.reshape(-1, pkg.qtypes.block_geometry(q)[1]), "f16", "bf16")
+            dense64[i] = torch.from_numpy(np.ascontiguousarray(w).view(np.int16).copy()).view(torch.bfloat16).reshape(rows, cols).double()
+        w64, x64 = dense64[i], x.double().cpu()
+        ref = x64 @ w64.T
+        tol = cols * 2.0 ** -24 * (x64.abs() @ w64.abs().T) + 2.0 ** -8 * ref.abs() + 1e-30
+        return bool(((y.double().cpu() - ref).abs() <= tol).all())
+
+    out = {"fused_small_m": {}, "fused_mfma": {}}
+    for group, ms in (("fused_small_m", (1, 4)), ("fused_mfma", (32, 64, 256))):
+        for m in ms:
+            xs = {}
+            for _, _, (rows, cols) in manifest:
+                if cols not in xs:
+                    xs[cols] = torch.randn(m, cols, device=device, dtype=dtype) * 0.05
+            taken, declined = [], []
+            for i, t in enumerate(tensors):
+                try:
+                    pkg.fused.linear_auto(xs[t.shape[1]], t)
+                    taken.append(i)
+                except unsupported:
+                    declined.append(i)
+            torch.cuda.synchronize(device)
+
+            def one_pass():
+                return [pkg.fused.linear_auto(xs[tensors[i].shape[1]], tensors[i]) for i in taken]
+            side = torch.cuda.Stream(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                keep = one_pass()
+                torch.cuda.synchronize(device)
+                with torch.cuda.graph(graph, stream=side):
+                    keep = one_pass()
+            graph.replay()
+            torch.cuda.synchronize(device)
+            ok = all(check(i, xs[tensors[i].shape[1]], keep[taken.index(i)]) for i in sample if i in taken)
+            regs = []
+            for _ in range(args.regions):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for _ in range(passes):
+                    graph.replay()
+                b.record(stream)
+                torch.cuda.synchronize(device)
+                regs.append(a.elapsed_time(b) / passes)
+            regs.sort()
+            ms_pass = regs[len(regs) // 2]
+            nbytes = sum(packed_of[i] for i in taken)
+            flops = sum(2.0 * m * manifest[i][2][0] * manifest[i][2][1] for i in taken)
+            gbs = nbytes / (ms_pass * 1e-3) / 1e9
+            kernels = sorted({("ggq::linear_small" if m <= pkg.fused.MAX_ROWS and manifest[i][2][1] <= 6144 else "ggq::linear_mfma16" if m <= 32 else "ggq::linear_mfma") for i in taken})
+            out[group][f"m={m}"] = {
+                "layers_fused": len(taken), "layers_declined": len(declined), "declined_shapes": sorted({"x".join(map(str, manifest[i][2])) for i in declined}),
+                "ms_per_pass": round(ms_pass, 4), "us_per_layer": round(ms_pass * 1e3 / max(1, len(taken)), 2), "regions_ms": [round(r, 4) for r in regs],
+                "TFLOPs": round(flops / (ms_pass * 1e-3) / 1e12, 1),
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": " + ".join(kernels), "algorithmic_bytes_per_pass": nbytes,
+                             "algorithmic_bytes": "packed bytes of every fused layer, read once (outputs: m x rows x 2 B, < 1 % of that)"},
+                "parity_vs_fp64_on_oracle_weights": f"within the fp32-accumulation bound ({sum(1 for i in sample if i in taken)} layers)" if ok else "OUTSIDE THE BOUND",
+            }
+            del graph, keep
+            torch.cuda.empty_cache()
+    out["how"] = (f"FLUX.1-dev {args.mix} linears ({len(manifest)} layers, {sum(packed_of) / 1e9:.2f} GB packed), bf16 input of m rows, the default policy fused.linear_auto per layer; "
+                  f"one pass captured as a HIP graph, median of {args.regions} regions of {passes} replays, HIP events on the replay stream")
+    return out
+
+
 def run_fused_error(pkg, device):
     """--workload fused-error: NOT a throughput line -- the numerics table install()'s default stands on (tools/fused_error.py measure(): fused linears vs
     unpack + F.linear, both against an fp64 product on the oracle's weights, every linear shape of FLUX.1-dev / SD3.5-large / T5-xxl x {1, 4, 64, 256} rows x
@@ -1007,7 +1107,7 @@ def main():
     ap.add_argument("--regions", type=int, default=3, help="timed regions of K steps each; the median region is reported")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the measured fill / copy / read ceilings (ggq_calibrate) beside the spec peak")
     ap.add_argument("--no-workloads", action="store_true", help="skip the configs[3] / configs[4] sub-lines of the default run")
-    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer", "fused-error"], help="see the module docstring")
+    ap.add_argument("--workload", default="pool", choices=["pool", "flux", "sd35-t5", "flux-gguf", "per-layer", "fused-error", "fused"], help="see the module docstring")
     ap.add_argument("--mix", default="Q4_K_M", help="quant mix of the flux workloads (manifests.flux_dev)")
     ap.add_argument("--upload-threads", type=int, default=0, help="flux-gguf: reader threads of the streaming upload (0 = default 8)")
     ap.add_argument("--limit-tensors", type=int, default=0, help="flux-gguf / per-layer: only the first N tensors (smoke runs, tests)")
@@ -1068,6 +1168,15 @@ def main():
             if world != 1:
                 sys.exit("--workload fused-error is a single-GPU measurement")
             result = run_fused_error(pkg, device)
+        elif args.workload == "fused":
+            if world != 1:
+                sys.exit("--workload fused is a single-GPU measurement")
+            fused = run_fused(pkg, args, device)
+            head = fused["fused_mfma"]["m=32"]
+            result = {"metric": "fused dequantize + linear, packed GB/s read (FLUX.1-dev set, 32 rows of x)", "value": head["roofline"]["achieved"], "unit": "GB/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_pass"], "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": {"workload": fused["how"]}, "roofline": head["roofline"],
+                      "workloads": {"fused_small_m": fused["fused_small_m"], "fused_mfma": fused["fused_mfma"]}}
         elif args.workload == "per-layer":
             if world != 1:
                 sys.exit("--workload per-layer is a single-GPU measurement")
@@ -1215,8 +1324,13 @@ def main():
                 args.steps = steps
                 subs["flux-gguf"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
+            # ... and the kernels that are install()'s default for SMALL inputs: the fused dequantize + linear launches, FLUX set, m = 1 / 4 and 32 / 64 / 256
+            # rows of x, each with its own packed-read roofline (Next #1: half of the default path had no driver-run measurement)
+            fused = run_fused(pkg, args, device)
+            subs["fused_small_m"], subs["fused_mfma"] = dict(fused["fused_small_m"], how=fused["how"]), dict(fused["fused_mfma"], how=fused["how"])
+            torch.cuda.empty_cache()
         elif rank == 0:
-            subs["per_layer"] = subs["flux-gguf"] = {"skipped": "single-GPU measurements: see the --gpus 1 line"}
+            subs["per_layer"] = subs["flux-gguf"] = subs["fused_small_m"] = subs["fused_mfma"] = {"skipped": "single-GPU measurements: see the --gpus 1 line"}
         if rank == 0:
             result["workloads"] = subs
     if rank == 0:

@@ -10,6 +10,7 @@ fp16) -- as hand-written HIP kernels for gfx950 behind a C-ABI shared library
     autoinstall the literal drop-in: this directory inside ComfyUI/custom_nodes/ finds ComfyUI-GGUF and calls install() on it
     grouped     DequantPlan: a whole weight set in one launch per quant type
     gguf_file   GGUF container reader (native parser) + file -> HBM streaming upload
+    gguf_adapter  gguf.GGUFReader as the reference's loader uses it, over gguf_file (install(native_reader=True))
     loader      gguf_sd_loader & co. (reference loader.py:16-141) without the `gguf` package
     resident    opt-in cache that keeps dequantized weights resident in HBM (288 GB make it possible)
     fused       fused dequantize + linear: 1-4 rows (modulation layers) and, on the matrix cores, up to 256 rows; install()'s default
@@ -28,7 +29,7 @@ __version__ = "0.1.0"
 # package adds NO nodes -- it accelerates the ones ComfyUI-GGUF registers ("Unet Loader (GGUF)" & co. keep working unchanged).
 NODE_CLASS_MAPPINGS = {}
 NODE_DISPLAY_NAME_MAPPINGS = {}
-_LAZY = ("_native", "autoinstall", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "loader", "resident", "fused", "overlap")
+_LAZY = ("_native", "autoinstall", "dequant", "install", "grouped", "sharding", "ops", "manifests", "gguf_file", "gguf_adapter", "loader", "resident", "fused", "overlap")
 
 
 def _running_under_comfyui():

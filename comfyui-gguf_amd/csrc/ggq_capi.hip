@@ -365,16 +365,6 @@ __global__ __launch_bounds__(256) void calibrate_kernel(const u32x4* __restrict_
 
 }  // namespace
 
-#ifdef GGQ_LAB
-int ggq::lab_int(const char* name, int lo, int hi)
-{
-    const char* e = getenv(name);
-    if (!e || !*e) return -1;
-    const int x = atoi(e);
-    return (x >= lo && x <= hi) ? x : -1;
-}
-#endif
-
 int ggq::hip_fail(hipError_t e)
 {
     t_last_hip = (int)e;

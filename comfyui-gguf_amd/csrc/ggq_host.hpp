@@ -12,7 +12,16 @@ int hip_fail(hipError_t e);
 // (tools/build_variant.py -DGGQ_LAB ...) compile the lookup in, so that one variant library can be A/B-ed over a knob on one box:
 // lab_int(name, lo, hi) = the integer value of environment variable `name` if set and within [lo, hi], else -1 (always -1 when shipped).
 #ifdef GGQ_LAB
-int lab_int(const char* name, int lo, int hi);
+}  // namespace ggq
+#include <cstdlib>
+namespace ggq {
+inline int lab_int(const char* name, int lo, int hi)      // header-only: a lab build may pass -DGGQ_LAB to ONE translation unit (tools/build_variant.py --unit)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return -1;
+    const int x = atoi(e);
+    return (x >= lo && x <= hi) ? x : -1;
+}
 #else
 constexpr int lab_int(const char*, int, int) { return -1; }
 #endif

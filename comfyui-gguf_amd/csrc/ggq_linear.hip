@@ -95,11 +95,34 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // ---- the MFMA kernel (ggq_mfma.hpp): tile = MB*32 rows of x  x  32 output columns; MB picked from m
 typedef hipError_t (*mfma_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, uint32_t, hipStream_t);
 
+// K-split width of the 32-row kernel: a launch parameter since round 6 (rounds 2-5: always 4 waves per workgroup).
+uint32_t mf_waves(uint32_t tiles, uint32_t n_spans, uint32_t slots, uint32_t min_kw, uint32_t max_kw);
+
 template <class F, int OUT, int MB>
 hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
     const dim3 grid((rows + 31u) / 32u, (m + (uint32_t)(MB * 32) - 1u) / (uint32_t)(MB * 32));
-    hipLaunchKernelGGL((linear_mfma<F, OUT, MB>), grid, dim3(MF_WAVES * 64), 0, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static const int lab_kw = lab_int("GGQ_MF32_KW", 1, 16);                         // lab builds only, read once (-1 in the shipped library)
+    constexpr uint32_t cap = (uint32_t)mf_max_waves(MB);
+    const uint32_t n_spans = (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN;
+    // Measured (profiles/r06_mfma32_ksplit_width_sweep.json, widths 4 / 6 / 8 / 12 at 32..256 rows of x): 4 waves stay best wherever the launch has a workgroup
+    // per CU or more -- the kernel is bound by its x loads through L2, not by latency -- and 8 win 8-12 % when it has fewer than 256 workgroups (3072-row weights)
+    uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : (grid.x * grid.y < 256u ? 8u : 4u);
+    if (kw > cap) kw = cap;
+    if (kw > n_spans) kw = n_spans;
+    const uint32_t lds = mf_lds_bytes<F, MB>(kw);
+    if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
+        static std::atomic<uint64_t> raised{0};
+        const uint64_t bit = 1ull << (dev & (MAX_DEVICES - 1));
+        if (!(raised.load(std::memory_order_relaxed) & bit)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma<F, OUT, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL((linear_mfma<F, OUT, MB>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
                        static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
     return hipGetLastError();
 }
@@ -107,13 +130,9 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
 // ---- the 16-row MFMA kernel (ggq_mfma16.hpp): tile = MB*16 rows of x  x  16 output columns, K split over KW waves of the workgroup.
 // KW: enough waves that every SIMD holds several (one wave's memory wait is another's issue slot), never more than the 256-element spans of a row,
 // and -- among the candidates -- the one whose slowest wave has the fewest spans; ties go to the smaller workgroup (less to sum at the end).
-uint32_t mf16_waves(uint32_t tiles, uint32_t n_spans, uint32_t cus, uint32_t min_kw)
+uint32_t mf_waves(uint32_t tiles, uint32_t n_spans, uint32_t slots, uint32_t min_kw, uint32_t max_kw)
 {
-    static const int lab_kw = lab_int("GGQ_MF16_KW", 1, MF16_MAX_WAVES);             // lab builds only, read once (-1 in the shipped library)
-    const uint32_t cap = n_spans < (uint32_t)MF16_MAX_WAVES ? n_spans : (uint32_t)MF16_MAX_WAVES;
-    if (lab_kw >= 1) return (uint32_t)lab_kw < min_kw ? min_kw : ((uint32_t)lab_kw > cap && cap >= min_kw ? cap : (uint32_t)lab_kw);
-    static const int lab_wps = lab_int("GGQ_MF16_WPS", 1, 8);
-    const uint32_t slots = cus * 4u * (lab_wps >= 1 ? (uint32_t)lab_wps : 6u);       // waves the chip holds at the kernels' register count
+    const uint32_t cap = n_spans < max_kw ? n_spans : max_kw;
     uint32_t best = min_kw, best_cost = ~0u;
     for (uint32_t kw = min_kw; kw <= (cap > min_kw ? cap : min_kw); kw++) {
         const uint32_t per_wave = (n_spans + kw - 1) / kw, rounds = (tiles * kw + slots - 1) / slots;
@@ -124,15 +143,18 @@ uint32_t mf16_waves(uint32_t tiles, uint32_t n_spans, uint32_t cus, uint32_t min
     return best;
 }
 
-template <class F, int OUT, int MB, bool XC, int NT>
+template <class F, int OUT, int MB>
 hipError_t launch_mfma16(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
 {
-    const dim3 grid((rows + (uint32_t)(NT * 16) - 1u) / (uint32_t)(NT * 16), (m + (uint32_t)(MB * 16) - 1u) / (uint32_t)(MB * 16));
+    const dim3 grid((rows + 15u) / 16u, (m + (uint32_t)(MB * 16) - 1u) / (uint32_t)(MB * 16));
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const uint32_t kw = mf16_waves(grid.x * grid.y, (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN, compute_units(dev), 2u);
-    const uint32_t lds = mf16_lds_bytes<F, MB, NT>(kw);
-    hipLaunchKernelGGL((linear_mfma16<F, OUT, MB, XC, NT>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed),
+    static const int lab_kw = lab_int("GGQ_MF16_KW", 1, MF16_MAX_WAVES);             // lab builds only, read once (-1 in the shipped library)
+    const uint32_t n_spans = (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN;
+    const uint32_t slots = compute_units(dev) * 4u * (MB == 1 ? 6u : 4u);            // waves the chip holds at this instantiation's register count
+    const uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : mf_waves(grid.x * grid.y, n_spans, slots, 2u, (uint32_t)MF16_MAX_WAVES);
+    const uint32_t lds = mf16_lds_bytes<F, MB>(kw);
+    hipLaunchKernelGGL((linear_mfma16<F, OUT, MB>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed),
                        static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
     return hipGetLastError();
 }
@@ -170,10 +192,9 @@ hipError_t launch_tile(const void* packed, const void* x, const void* bias, void
     return launch_tile_wm<F, OUT, GGQ_TILE_WM_DEFAULT>(packed, x, bias, y, m, rows, cols, s);
 }
 
-constexpr int MFMA_SHAPES = 12;                   // MB = 1, 2, 4 (K-split kernel), the 256 x 256 shared-tile kernel, then the 16-row kernel with one / two blocks of x
+constexpr int MFMA_SHAPES = 6;                   // MB = 1, 2, 4 (K-split kernel), the 256 x 256 shared-tile kernel, then the 16-row kernel with one / two blocks of x
 struct MfmaEntry { int qtype, block_size, type_size; mfma_fn fn[2][MFMA_SHAPES]; };   // [dtype f16 / bf16][shape]
-#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>, launch_mfma16<F, OUT, 1, false, 1>, launch_mfma16<F, OUT, 2, false, 1>, launch_mfma16<F, OUT, 1, true, 1>, launch_mfma16<F, OUT, 2, true, 1>, \
-                            launch_mfma16<F, OUT, 1, false, 2>, launch_mfma16<F, OUT, 2, false, 2>, launch_mfma16<F, OUT, 1, true, 2>, launch_mfma16<F, OUT, 2, true, 2>}
+#define GGQ_MF_ROW(F, OUT) {launch_mfma<F, OUT, 1>, launch_mfma<F, OUT, 2>, launch_mfma<F, OUT, 4>, launch_tile<F, OUT>, launch_mfma16<F, OUT, 1>, launch_mfma16<F, OUT, 2>}
 #define GGQ_MF(F) MfmaEntry { F::ID, F::BS, F::TS, {GGQ_MF_ROW(F, OUT_F16), GGQ_MF_ROW(F, OUT_BF16)} }
 const MfmaEntry MFMA[] = {
     GGQ_MF(FmtQ4_0), GGQ_MF(FmtQ4_1), GGQ_MF(FmtQ5_0), GGQ_MF(FmtQ5_1), GGQ_MF(FmtQ8_0),
@@ -215,11 +236,13 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
         // caller's question (fused.linear_mfma declines above 256 rows of x unless a tile is forced: profiles/r04_gemm_skeleton_sweep.json).
         const uint32_t n_tiles = ((m + GT_BM - 1) / GT_BM) * ((rows + GT_BN - 1) / GT_BN);
         const bool tile_ok = !k_tail && m >= tile_min_m() && rows % 8u == 0 && rows <= (1u << 22) && aligned16(y) && n_tiles >= 80u;
-        shape = m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2));
+        // the 16-row kernel (ggq_mfma16.hpp, round 6) where it measured faster than the 32-row one: up to 8 rows of x on every weight, up to 16 rows on weights
+        // of at most 4096 rows (few 32-row tiles: 96 workgroups for FLUX's 3072 x 12288).  Beyond that its x loads (every workgroup reads all of x for 16
+        // output columns) cost more than the 32-row tile's wasted MFMA rows: profiles/r06_mfma16_variants_kmap_and_blocks_per_wave.json
+        const bool use16 = m <= 8 || (m <= 16 && rows <= 4096u);
+        shape = use16 ? 4 : (m <= 32 ? 0 : (tile_ok ? 3 : (m < 384 ? 1 : 2)));
     }
-    // the 16-row kernel (ggq_mfma16.hpp): one block of 16 rows of x per tile up to m = 16, else two.  16 = its sub-block-per-lane k map, 17 = its x-contiguous map,
-    // 18 / 19 = the same two with TWO 16-row blocks of W per wave (32 output columns per workgroup)
-    else if (tile_rows >= 16 && tile_rows <= 19) shape = (m <= 16 ? 4 : 5) + ((tile_rows & 1) ? 2 : 0) + (tile_rows >= 18 ? 4 : 0);
+    else if (tile_rows == 16) shape = m <= 16 ? 4 : 5;              // the 16-row kernel (ggq_mfma16.hpp): one block of 16 rows of x per tile, else two (grid.y tiles beyond 32 rows)
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
     else return GGQ_ERR_ARG;
     if (shape == 3 && (k_tail || rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;   // whole spans only; 16-byte pieces of y; 32-bit offsets inside a tile's rows of y

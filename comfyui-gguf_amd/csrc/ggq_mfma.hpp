@@ -48,13 +48,17 @@ GGQ_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c)
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-constexpr int MF_WAVES = 4;       // waves per workgroup = K-split factor
+constexpr int MF_WAVES = 4;       // waves per workgroup = K-split factor of rounds 2-5; since round 6 the launch picks 4..16 (blockDim.x / 64): see mf_lds_bytes / ggq_linear.hip
+constexpr int mf_max_waves(int mb) { return mb == 1 ? 12 : (mb == 2 ? 8 : 4); }   // the register budget of a workgroup's waves: 170 / 256 / 512 per lane
 constexpr int MF_SPAN = 256;      // contraction elements per span (one K-quant super-block, 8 legacy blocks)
 
 template <class F> struct MfmaGeom {
     static constexpr int SPAN_BYTES = MF_SPAN / F::BS * F::TS;                     // packed bytes of one row's span
-    // a span may start at any 2-byte boundary (Q6_K 210 B, Q3_K 110 B, ...): every row keeps its own leading misalignment
-    static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0;
+    // a span may start at any 2-byte boundary (Q6_K 210 B, Q3_K 110 B, ...): every row keeps its own leading misalignment.  The 32-element formats count as
+    // unaligned too: with a short last span (cols % 256 != 0: SD3.5's 2432 columns) a ROW is no longer a multiple of 16 bytes (Q5_0: 1672), so the rows of a
+    // tile start at different offsets mod 16 although every span is 176 bytes (treating them as aligned made the 16-byte loads of odd rows
+    // start unaligned and the last one reach up to 12 bytes past the row -- past the tensor on its last row)
+    static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0 && F::BS != 32;
     static constexpr int U = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;         // 16-byte load units per row
     static constexpr int ROW_STRIDE = U * 16;
     static constexpr int NUW = (32 * U + 63) / 64;                                 // load units per lane
@@ -78,8 +82,16 @@ template <class F> struct MfmaGeom {
 constexpr int MF_XPITCH = 64;
 GGQ_DEV uint32_t mf_swz(uint32_t row) { return (row >> 3) & 3u; }
 
+// LDS bytes of a workgroup of `kw` waves: per wave its slice of packed bytes (+ its piece of x when MB >= 2) during the main loop, one accumulator block
+// (16 registers x 64 lanes x 4 B) per wave for the reduction after it
+template <class F, int MB> constexpr uint32_t mf_lds_bytes(uint32_t kw)
+{
+    const uint32_t per_wave = (uint32_t)MfmaGeom<F>::SLICE + (MB >= 2 ? (uint32_t)(MB * 32 * 64) : 0u), red = 16u * 64u * 4u;
+    return kw * (per_wave > red ? per_wave : red);
+}
+
 template <class F, int OUT, int MB>
-__global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+__global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                              const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
                                                              uint32_t m, uint32_t n_rows, uint32_t cols)
 {
@@ -90,9 +102,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
     constexpr bool XLDS = MB >= 2;
     constexpr int XS = XLDS ? MB * 32 * MF_XPITCH : 0;                             // LDS bytes per wave for its piece of x
     constexpr int PER_WAVE = G::SLICE + XS;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[(MF_WAVES * PER_WAVE > MF_WAVES * RED) ? MF_WAVES * PER_WAVE : MF_WAVES * RED];
+    static_assert(RED == 16 * 64 * 4 && (MB < 2 || XS == MB * 32 * 64), "mf_lds_bytes() restates these");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                 // mf_lds_bytes<F, MB>(kw)
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t kw = blockDim.x >> 6;                                           // waves of this workgroup = K-split factor (4..16, the launch's choice)
     const int lane = (int)(threadIdx.x & 63);
     const int r = lane & 31, h = lane >> 5;
     const uint32_t n0 = blockIdx.x * 32u, m0 = blockIdx.y * (uint32_t)(MB * 32);
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
             const uint64_t off = (uint64_t)rr * row_bytes + (uint64_t)span * G::SPAN_BYTES;
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)off & 15u);
             const uint32_t span_bytes = span_len(span) / (uint32_t)F::BS * (uint32_t)F::TS;       // == SPAN_BYTES but for a short last span
-            // the last unit of a row may reach past the row's span by < 16 bytes inside its aligned 16-byte unit: same page, never faults
+            // every load starts 16-byte aligned (off - a), so what it reads past the row's span (< 16 bytes) lies inside an aligned unit that also holds bytes of the tensor
             pf[u] = (ur < 32u && uu * 16u < a + span_bytes) ? gload16<false>(packed + (off - a) + uu * 16u) : u32x4{0, 0, 0, 0};
         }
     };
@@ -150,11 +164,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
     if constexpr (!XLDS) {
         const uint32_t mr = m0 + (uint32_t)r;
         const GGQ_GLOBAL uint8_t* xrow = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
-        for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
+        for (uint32_t span = (uint32_t)wave; span < n_spans; span += kw) {
 #pragma unroll
             for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
             wave_sync();
-            if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);             // the next span's bytes fly while this one is decoded
+            if (span + kw < n_spans) fetch(span + kw, pf);                         // the next span's bytes fly while this one is decoded
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
             const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
@@ -188,23 +202,23 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
         const uint32_t swr = mf_swz((uint32_t)r);                                  // rows 32 mb + r swizzle like row r
         u32x4 ring[2][NX];                                                         // pieces g and g+1 in flight while piece g-1 is consumed
         auto xfetch = [&](uint32_t piece, u32x4 (&dst)[NX]) {                      // piece = index over the wave's own sequence of 32-element pieces
-            // the wave's p-th piece: span = wave + 4 (p / 8), t = p % 8
-            const uint32_t kb = (((uint32_t)wave + MF_WAVES * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
+            // the wave's p-th piece: span = wave + kw (p / 8), t = p % 8
+            const uint32_t kb = (((uint32_t)wave + kw * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
 #pragma unroll
             for (int i = 0; i < NX; i++) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
         };
-        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + MF_WAVES - 1) / MF_WAVES : 0u;
+        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + kw - 1) / kw : 0u;
         // 8 pieces of 32 elements per span; the wave that owns the LAST span has fewer in it when that span is short
-        const bool owns_last = my_spans > 0 && (uint32_t)wave + MF_WAVES * (my_spans - 1) == n_spans - 1;
+        const bool owns_last = my_spans > 0 && (uint32_t)wave + kw * (my_spans - 1) == n_spans - 1;
         const uint32_t my_pieces = my_spans * 8u - (owns_last ? (uint32_t)(MF_SPAN - tail_len) / 32u : 0u);
         if (my_pieces > 0) xfetch(0u, ring[0]);
         if (my_pieces > 1) xfetch(1u, ring[1]);
         uint32_t piece = 0;
-        for (uint32_t span = (uint32_t)wave; span < n_spans; span += MF_WAVES) {
+        for (uint32_t span = (uint32_t)wave; span < n_spans; span += kw) {
 #pragma unroll
             for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
             wave_sync();
-            if (span + MF_WAVES < n_spans) fetch(span + MF_WAVES, pf);
+            if (span + kw < n_spans) fetch(span + kw, pf);
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
             const uint32_t len = span_len(span);
@@ -228,10 +242,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
         }
     }
 
-    // ---- sum the four K-partials through LDS, fixed order (wave 0 + 1 + 2 + 3), then bias, cast, store.
+    // ---- sum the kw K-partials through LDS, fixed order (wave 0 + 1 + ... ), then bias, cast, store.
     // C/D layout of the 32x32 MFMA: register i of lane l holds D[row = (i & 3) + 8 (i >> 2) + 4 (l >> 5)][col = l & 31]; here row = row
     // of x inside its 32-block, col = output column.  In round mb every wave parks its accumulator block; wave w then finishes registers
-    // 4w .. 4w+3 of the block for all lanes.
+    // w, w + kw, ... of the block for all lanes.
     float bias = 0.0f;
     const uint32_t ncol = n0 + (uint32_t)r;
     if (bias_ != nullptr && ncol < n_rows) {
@@ -246,15 +260,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void linear_mfma(const uint8_t* __re
 #pragma unroll
         for (int i = 0; i < 16; i++) red[(wave * 16 + i) * 64 + lane] = acc[mb][i];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = wave * 4 + k;
-            float v = red[(0 * 16 + i) * 64 + lane];
-            v += red[(1 * 16 + i) * 64 + lane];
-            v += red[(2 * 16 + i) * 64 + lane];
-            v += red[(3 * 16 + i) * 64 + lane];
+        for (uint32_t i = (uint32_t)wave; i < 16u; i += kw) {
+            float v = red[i * 64 + lane];
+            for (uint32_t w = 1; w < kw; w++) v += red[((w * 16u + i) * 64u) + lane];
             v += bias;
-            const uint32_t mr = m0 + (uint32_t)(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h);
+            const uint32_t mr = m0 + (uint32_t)(mb * 32) + (i & 3u) + 8u * (i >> 2) + 4u * (uint32_t)h;
             if (mr < m && ncol < n_rows) {
                 uint16_t o;
                 if constexpr (OUT == OUT_F16) o = __builtin_bit_cast(uint16_t, (_Float16)v);

@@ -57,10 +57,17 @@ def hip_supported(qtype):
     return _qtype_key(qtype) in HIP_QTYPES
 
 
+def _is_compiling():
+    c = getattr(torch, "compiler", None)
+    return bool(c and hasattr(c, "is_compiling") and c.is_compiling())
+
+
 def _as_bytes(data, align=True):
     """dequant.py:37-39: rows = data.reshape((-1, data.shape[-1])).view(torch.uint8), flattened."""
-    if type(data) is not torch.Tensor:
-        data = data.as_subclass(torch.Tensor)          # strip GGMLTensor: plain byte buffer from here on
+    if type(data) is not torch.Tensor and not _is_compiling():
+        # strip GGMLTensor: plain byte buffer from here on.  (Not while torch.compile traces: Dynamo cannot trace `as_subclass(torch.Tensor)` -- a graph break per
+        # layer in rounds 2-5 -- and does not need it: the subclass rides through reshape / view into the custom op, whose result the caller strips.)
+        data = data.as_subclass(torch.Tensor)
     if data.dtype != torch.uint8:
         data = data.reshape((-1, data.shape[-1])).view(torch.uint8)
     data = data.reshape(-1)
@@ -166,11 +173,6 @@ except (AttributeError, RuntimeError):       # torch without torch.library.custo
     _dequantize_op = None
 
 
-def _is_compiling():
-    c = getattr(torch, "compiler", None)
-    return bool(c and hasattr(c, "is_compiling") and c.is_compiling())
-
-
 # qtype (IntEnum member of this package, of the gguf package, or a plain int: all hash alike) ->
 # (ggml type id, block_size, type_size)
 _HIP_TABLE = {k: (int(k),) + tuple(GGML_QUANT_SIZES[k]) for k in HIP_QTYPES}
@@ -190,8 +192,9 @@ def _dequant_hip(data, qtype, out_dtype, compute=None, oshape=None, entry=None):
     compute_code = _check_compute(compute)
     out_code = _OUT_CODE[out_dtype]
     if _dequantize_op is not None and _is_compiling():
-        res = _dequantize_op(_as_bytes(data, align=False), qid, compute_code, out_code)
-        return res if oshape is None else res.reshape(oshape)
+        with _NoTorchFunction():                            # (the GGMLTensor subclass must not claim the result: a plain dense tensor comes back)
+            res = _dequantize_op(_as_bytes(data, align=False), qid, compute_code, out_code)
+            return res if oshape is None else res.reshape(oshape)
     with _NoTorchFunction():
         if not data.is_cuda:
             raise GGQUnsupported(f"packed data is on {data.device}; the HIP path serves GPU-resident weights only")
@@ -409,6 +412,9 @@ except (AttributeError, RuntimeError):
     _dequantize_rows_op = None
 
 
+_TRACE_ANY_DEVICE = False      # tests only (see fused._TRACE_ANY_DEVICE)
+
+
 def dequantize_rows_traced(tensor, indices, dtype, dequant_dtype, check_indices):
     """``dequantize_rows`` while torch.compile traces install()'s Embedding wrapper: the custom op, or None when the eager call would have raised
     GGQUnsupported (the caller then traces the reference's method).  Conditions on trace-time constants only."""
@@ -422,12 +428,13 @@ def dequantize_rows_traced(tensor, indices, dtype, dequant_dtype, check_indices)
     out_dtype = _COMPUTE_TORCH[cd] if dtype is None else dtype
     qid, block_size, type_size = _HIP_TABLE[key]
     n_rows, cols = int(shape[0]), int(shape[1])
-    if out_dtype not in _OUT_CODE or cols % block_size or not tensor.is_cuda or not indices.is_cuda or indices.dtype not in (torch.int64, torch.int32):
+    if out_dtype not in _OUT_CODE or cols % block_size or not ((tensor.is_cuda and indices.is_cuda) or _TRACE_ANY_DEVICE) or indices.dtype not in (torch.int64, torch.int32):
         return None
-    packed = _as_bytes(tensor, align=False)
-    if packed.numel() != n_rows * (cols // block_size) * type_size:
-        return None
-    return _dequantize_rows_op(packed, indices, qid, n_rows, cols, _COMPUTE_CODE[cd], _OUT_CODE[out_dtype], bool(check_indices))
+    with _NoTorchFunction():
+        packed = _as_bytes(tensor, align=False)
+        if packed.numel() != n_rows * (cols // block_size) * type_size:
+            return None
+        return _dequantize_rows_op(packed, indices, qid, n_rows, cols, _COMPUTE_CODE[cd], _OUT_CODE[out_dtype], bool(check_indices))
 
 
 # ---- dequantize_functions: the reference's per-format block functions (dequant.py:287-301) --------

@@ -145,7 +145,7 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
     kernel) or ``auto_max_rows=None`` forces the fused kernel at any size."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
-    if tile_rows not in (0, 16, 17, 18, 19, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
+    if tile_rows not in (0, 16, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
         raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 16, 32, 64, 128 or 256 (the shared-tile kernel: rows % 8 == 0, cols % 256 == 0)")
     if tile_rows == 0 and auto_max_rows is not None and (m > auto_max_rows or (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)):
         raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x on {rows} output columns -- dequantize + F.linear is the faster path there "
@@ -153,6 +153,35 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     if _mfma_call is None:
         _bind()
     return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)
+
+
+SMALL_M_TALL_ROWS = 16384     # one row of x: from this many output columns on the 16-row MFMA kernel is ahead of the GEMV
+
+
+def _tall(weight):
+    shape = getattr(weight, "tensor_shape", ())
+    return len(shape) == 2 and shape[0] >= SMALL_M_TALL_ROWS
+
+
+def linear_auto(x, weight, bias=None, dequant_dtype=None, weight_to=None, small_m=True, mfma_max_m=AUTO_MAX_ROWS):
+    """The policy of install()'s default in one place (install._fuse_linear, bench.py's fused workloads, the forward emulations): which fused kernel
+    takes ``F.linear(x, dequantize_tensor(weight, x.dtype), bias)`` for this many rows of x, or GGQUnsupported when none does (the caller keeps
+    dequantize + F.linear).  One row -> ``linear_small`` when ``small_m`` (shapes it declines, and weights of 16384+ rows, go to the MFMA kernels); 2..``mfma_max_m``
+    rows -> ``linear_mfma`` with the library's choice of kernel and tile (16-row kernel up to 8 rows of x, 32-row kernel above; ggq_linear.hip)."""
+    cols = x.shape[-1]
+    m = x.numel() // cols if cols else 0
+    # one row: the GEMV (level with the 16-row MFMA kernel up to ~12 k output columns, ahead on the shorter weights: 9.2 vs 10.2 us at 9216 x 3072; also the only
+    # one that takes fp32 activations); two to four rows, and one row on the tallest weights: the MFMA kernel, whose time does not grow with m
+    # (12288 x 3072: 11.0 us at 4 rows against the GEMV's 17.1; 18432 x 3072 at one row 14.5 against 15.6 -- profiles/r06_mfma16_variants_kmap_and_blocks_per_wave.json)
+    if small_m and m <= MAX_ROWS and not (mfma_max_m and x.dtype in (_F16, _BF16) and (m > 1 or _tall(weight))):
+        try:
+            return linear_small(x, weight, bias, dequant_dtype, weight_to=weight_to)
+        except GGQUnsupported:
+            if not mfma_max_m:
+                raise
+    if m <= mfma_max_m:
+        return linear_mfma(x, weight, bias, dequant_dtype, weight_to=weight_to, auto_max_rows=mfma_max_m)
+    raise GGQUnsupported(f"fused linears: {m} rows of x is above the {mfma_max_m} the default fuses")
 
 
 # ---- torch.compile: the fused launches as opaque custom ops ------------------------------------------------------------------------------
@@ -215,12 +244,15 @@ except (AttributeError, RuntimeError):       # torch without torch.library.custo
     _linear_small_op = _linear_mfma_op = None
 
 
+_TRACE_ANY_DEVICE = False      # tests only: lets the CPU suite trace the default install over stub CPU kernels of the custom ops (graph-break count without a GPU)
+
+
 def linear_traced(layer, x, small_m, mfma_max_m):
     """install()'s Linear wrapper while torch.compile traces it: the fused custom op for this layer and input, or None when the eager wrapper
     would have handed the call to the reference's method (the caller then traces that).  Mirrors `_prepare` + `linear_small` / `linear_mfma(auto)`;
     every condition here is on trace-time constants."""
     weight, bias = layer.weight, layer.bias
-    if _linear_small_op is None or weight is None or not x.is_cuda:
+    if _linear_small_op is None or weight is None or not (x.is_cuda or _TRACE_ANY_DEVICE):
         return None
     dd = layer.dequant_dtype
     if dd is not None and dd is not _F16:
@@ -240,7 +272,7 @@ def linear_traced(layer, x, small_m, mfma_max_m):
     m = x.numel() // cols
     if bias is not None and bias.numel() != rows:
         return None
-    small = small_m and m <= MAX_ROWS and x.dtype in _OUT_CODE
+    small = small_m and m <= MAX_ROWS and x.dtype in _OUT_CODE and not (mfma_max_m and x.dtype in (_F16, _BF16) and (m > 1 or rows >= SMALL_M_TALL_ROWS))
     if small:
         row_bytes = cols // block_size * type_size
         slice_bytes = (row_bytes + 15 + 1023) & ~1023
@@ -253,13 +285,12 @@ def linear_traced(layer, x, small_m, mfma_max_m):
             return None
     if weight.device != x.device:
         weight = weight.to(x.device)                                     # low-VRAM mode: the copy the reference's method makes (ops.py:209)
-    packed = _as_bytes(weight, align=False)
-    if bias is not None:
-        if is_quantized(bias):
-            bias = dequantize_tensor(bias, x.dtype)                      # (traced: the ggq::dequantize custom op)
-        if type(bias) is not torch.Tensor:
-            bias = bias.as_subclass(torch.Tensor)
-        bias = bias.to(device=x.device, dtype=x.dtype)
-    if small:
-        return _linear_small_op(x, packed, bias, qid, rows, cols)
-    return _linear_mfma_op(x, packed, bias, qid, rows, cols, 0)
+    if bias is not None and is_quantized(bias):
+        bias = dequantize_tensor(bias, x.dtype)                          # (traced: the ggq::dequantize custom op)
+    with torch._C.DisableTorchFunctionSubclass():                        # the GGMLTensor operands must not claim the result (and Dynamo cannot trace as_subclass)
+        packed = _as_bytes(weight, align=False)
+        if bias is not None:
+            bias = bias.to(device=x.device, dtype=x.dtype)
+        if small:
+            return _linear_small_op(x, packed, bias, qid, rows, cols)
+        return _linear_mfma_op(x, packed, bias, qid, rows, cols, 0)

@@ -38,6 +38,10 @@ callers, token_embd / mmproj tables (reference loader.py:253-254,270,386,397) --
 (dequant.dequantize_tensor_via_gpu) instead of running the reference's torch-CPU ops: same bits, CPU result.  Off by default (it
 touches the GPU at load time, before ComfyUI's model management has placed anything).
 
+``native_reader`` (or ``GGQ_NATIVE_READER=1``; needs ``ref_loader``): the GGUF container behind "Unet Loader (GGUF)" is parsed by the native reader
+(include/ggq_gguf.h) instead of gguf-py's ``GGUFReader`` -- the reference's ``gguf_sd_loader`` runs unchanged over an adapter that yields what
+loader.py:55-106 reads (gguf_adapter.py: CPU mmap views, same ownership and semantics).  Opt-in.
+
 ``fast`` (or ``GGQ_FAST=1``): ``fused_small_m`` + ``fused_mfma`` + ``gather_embedding`` in one switch -- the options that hold no VRAM and measured faster
 wherever they apply.  The default when ``ref_ops`` is given; ``exact`` (``GGQ_EXACT=1``) is its opposite.
 
@@ -76,7 +80,7 @@ def _env_flag(name):
 
 
 def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fused_small_m=None, gather_embedding=None, overlap=None,
-            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, fast=None, exact=None):
+            fused_mfma=None, fused_mfma_max_m=None, cpu_route_mb=None, fast=None, exact=None, native_reader=None):
     """Patch the reference modules in place; returns the dict of original functions.
 
     ``fast`` (or ``GGQ_FAST=1``; needs ``ref_ops``): ``fused_small_m`` + ``fused_mfma`` (same weights, results as close to the exact product as
@@ -140,41 +144,76 @@ def install(ref_dequant, ref_ops=None, ref_loader=None, dense_cache_gb=None, fus
 
     dequantize.__wrapped__ = orig["dequantize"]
     dequantize_tensor.__wrapped__ = orig["dequantize_tensor"]
-    ref_dequant.dequantize = dequantize
-    ref_dequant.dequantize_tensor = dequantize_tensor
-    patched = [(ref_dequant, "dequantize", orig["dequantize"]), (ref_dequant, "dequantize_tensor", orig["dequantize_tensor"])]
-    for mod in (ref_ops, ref_loader):               # `from .dequant import dequantize_tensor` bound the old object
-        if mod is not None and getattr(mod, "dequantize_tensor", None) is orig["dequantize_tensor"]:
-            mod.dequantize_tensor = dequantize_tensor
-            patched.append((mod, "dequantize_tensor", orig["dequantize_tensor"]))
     if fused_small_m is None:
         fused_small_m = _env_flag("GGQ_FUSED_SMALL_M")
     if fused_mfma is None:
         fused_mfma = _env_flag("GGQ_FUSED_MFMA")
     if fused_mfma_max_m is None:
         fused_mfma_max_m = int(os.environ.get("GGQ_FUSED_MFMA_MAX_M", "256"))
+    if gather_embedding is None:
+        gather_embedding = _env_flag("GGQ_GATHER_EMBEDDING")
+    if overlap is None:
+        overlap = _env_flag("GGQ_OVERLAP")
+    if native_reader is None:
+        native_reader = _env_flag("GGQ_NATIVE_READER")
+    if native_reader and (ref_loader is None or not hasattr(ref_loader, "gguf")):
+        raise ValueError("native_reader rebinds the name `gguf` inside the reference's loader module (loader.py:5,55): pass ref_loader")
+    # Everything an option needs is looked up BEFORE the first attribute is replaced, and the replacing itself is undone if any step fails: a
+    # ComfyUI-GGUF checkout that lacks one of the classes must not be left half-patched with `_installed` unwritten (uninstall() could then restore
+    # nothing).  Options that only came from the DEFAULT (nobody asked for them by name) are skipped when their class is absent.
+    ggml_ops = getattr(ref_ops, "GGMLOps", None) if ref_ops is not None else None
+    explicit = asked_fast is not None                 # `fast` given by argument or GGQ_FAST: its parts are then requests, not defaults
     if fused_small_m or fused_mfma:
         if ref_ops is None:
             raise ValueError("fused_small_m / fused_mfma patch GGMLOps.Linear: pass ref_ops")
-        patched.append(_fuse_linear(ref_ops.GGMLOps.Linear, unsupported, bool(fused_small_m), fused_mfma_max_m if fused_mfma else 0))
-    if gather_embedding is None:
-        gather_embedding = _env_flag("GGQ_GATHER_EMBEDDING")
+        if not hasattr(getattr(ggml_ops, "Linear", None), "forward_ggml_cast_weights"):
+            if explicit or not fast:
+                raise AttributeError("this ComfyUI-GGUF checkout has no GGMLOps.Linear.forward_ggml_cast_weights to wrap (fused_small_m / fused_mfma)")
+            fused_small_m = fused_mfma = False
     if gather_embedding:
         if ref_ops is None:
             raise ValueError("gather_embedding patches GGMLOps.Embedding: pass ref_ops")
-        patched.append(_gather_embedding(ref_ops.GGMLOps.Embedding, unsupported))
-    if overlap is None:
-        overlap = _env_flag("GGQ_OVERLAP")
+        if not hasattr(getattr(ggml_ops, "Embedding", None), "forward_ggml_cast_weights"):
+            if explicit or not fast:
+                raise AttributeError("this ComfyUI-GGUF checkout has no GGMLOps.Embedding.forward_ggml_cast_weights to wrap (gather_embedding)")
+            gather_embedding = False
+    if overlap and ref_ops is None:
+        raise ValueError("overlap patches GGMLLayer.cast_bias_weight: pass ref_ops")
+    patched = []
     prefetcher = None
-    if overlap:
-        if ref_ops is None:
-            raise ValueError("overlap patches GGMLLayer.cast_bias_weight: pass ref_ops")
-        from .overlap import attach
-        record, prefetcher = attach(ref_ops.GGMLLayer)
-        patched.append(record)
+
+    def put(owner, name, new):
+        patched.append((owner, name, getattr(owner, name)))
+        setattr(owner, name, new)
+
+    try:
+        put(ref_dequant, "dequantize", dequantize)
+        put(ref_dequant, "dequantize_tensor", dequantize_tensor)
+        for mod in (ref_ops, ref_loader):               # `from .dequant import dequantize_tensor` bound the old object
+            if mod is not None and getattr(mod, "dequantize_tensor", None) is orig["dequantize_tensor"]:
+                put(mod, "dequantize_tensor", dequantize_tensor)
+        if fused_small_m or fused_mfma:
+            patched.append(_fuse_linear(ggml_ops.Linear, unsupported, bool(fused_small_m), fused_mfma_max_m if fused_mfma else 0))
+        if gather_embedding:
+            patched.append(_gather_embedding(ggml_ops.Embedding, unsupported))
+        if overlap:
+            from .overlap import attach
+            record, prefetcher = attach(ref_ops.GGMLLayer)
+            patched.append(record)
+        if native_reader:
+            # "Unet Loader (GGUF)" -> loader.gguf_sd_loader -> gguf.GGUFReader(path) (loader.py:55): the container is parsed by the C++ reader of
+            # include/ggq_gguf.h, handed to the reference's UNCHANGED loader in gguf-py's attribute layout (CPU mmap views, same ownership)
+            from .gguf_adapter import GGUFModuleProxy
+            put(ref_loader, "gguf", GGUFModuleProxy(ref_loader.gguf))
+    except BaseException:
+        for owner, name, fn in reversed(patched):
+            setattr(owner, name, fn)
+        if prefetcher is not None:
+            prefetcher.close()
+        raise
     options = {"dense_cache_gb": dense_cache_gb or None, "fused_small_m": bool(fused_small_m) or None, "fused_mfma": (fused_mfma_max_m if fused_mfma else None),
                "gather_embedding": bool(gather_embedding) or None, "overlap": bool(overlap) or None, "cpu_route_mb": cpu_route_mb or None,
-               "exact": bool(exact) or None}
+               "exact": bool(exact) or None, "native_reader": bool(native_reader) or None}
     rec = {"orig": orig, "patched": patched, "cache": cache, "prefetcher": prefetcher,
            "options": {k: v for k, v in options.items() if v is not None}}
     if (dense_cache_gb or overlap) and ref_ops is not None and hasattr(getattr(ref_ops, "GGMLLayer", None), "ggml_save_to_state_dict"):
@@ -259,7 +298,7 @@ def _gather_embedding(embedding_cls, unsupported):
 
     def forward_ggml_cast_weights(self, input, out_dtype=None):
         weight = self.weight
-        if (input.is_cuda and weight is not None and getattr(self, "max_norm", None) is None
+        if ((input.is_cuda or (is_compiling() and _hip._TRACE_ANY_DEVICE)) and weight is not None and getattr(self, "max_norm", None) is None
                 and not getattr(weight, "patches", None)):
             # the table's dtype the reference's way: out_dtype, else what cast_bias_weight(self, ...) falls back to (ops.py:196-197)
             table_dtype = out_dtype if out_dtype is not None else getattr(self, "dtype", torch.float32)
@@ -281,7 +320,7 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
     """Wrap ``linear_cls.forward_ggml_cast_weights``: inputs of 1..4 rows -> fused.linear_small (when ``small_m``), inputs of up
     to ``mfma_max_m`` rows -> fused.linear_mfma; everything else, and everything either kernel declines, -> the reference's method.
     Returns the (owner, name, original) record uninstall() restores."""
-    from .fused import MAX_ROWS, linear_mfma, linear_small, linear_traced
+    from .fused import linear_auto, linear_traced
     reference_forward = linear_cls.forward_ggml_cast_weights
     is_compiling = _hip._is_compiling
 
@@ -293,15 +332,10 @@ def _fuse_linear(linear_cls, unsupported, small_m, mfma_max_m):
             y = linear_traced(self, input, small_m, mfma_max_m)
             return y if y is not None else reference_forward(self, input)
         if weight is not None and input.is_cuda:
-            cols = input.shape[-1]
-            m = input.numel() // cols if cols else 0
             try:
                 # a CPU-resident weight (low-VRAM mode) is copied to the GPU only once the kernel is known to take the request
                 # (weight_to): a declined request costs no copy, the reference's method below makes its own (ops.py:209)
-                if small_m and m <= MAX_ROWS:
-                    return linear_small(input, weight, self.bias, self.dequant_dtype, weight_to=input.device)
-                if m <= mfma_max_m:
-                    return linear_mfma(input, weight, self.bias, self.dequant_dtype, weight_to=input.device, auto_max_rows=mfma_max_m)
+                return linear_auto(input, weight, self.bias, self.dequant_dtype, input.device, small_m, mfma_max_m)
             except unsupported:
                 pass
         return reference_forward(self, input)

@@ -1,0 +1,16 @@
+# round 6, session g: linear_mfma16s (x shared through LDS, 4 / 2 blocks of W per workgroup = tile 20 / 21) -- parity, times vs tile 16 and the 32-row kernel, K-split width
+O=gpurun_out/r6g; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_mfma.py -x -q -k "mfma16 or exact or short_last or randomized" > $O/tests.log 2>&1; echo rc=$? >> $O/tests.log; tail -4 $O/tests.log
+timeout 900 python tools/fused_sweep.py --m 8,16,32 --kernels mfma:0,mfma:16,mfma:20,mfma:21 --shapes 12288x3072,18432x3072,3072x12288,21504x3072,3072x3072,9216x3072 > $O/sweep.json 2> $O/sweep.err; cat $O/sweep.err | cut -c1-330
+export GGQ_HIP_LIB=$PWD/gpurun_tmp_libs/libggq_lab.so
+for kw in 1 2 3 4; do
+  GGQ_MF16S_KW=$kw timeout 600 python tools/fused_sweep.py --m 16,32 --kernels mfma:20,mfma:21 --shapes 12288x3072,3072x12288,21504x3072 > $O/kw$kw.json 2> $O/kw$kw.err
+done
+python - <<'PY'
+import json
+tab={}
+for kw in (1,2,3,4):
+    for r in json.load(open(f"gpurun_out/r6g/kw{kw}.json"))["rows"]:
+        for k in ("mfma:20","mfma:21"): tab.setdefault((r["weight"],r["m"],k),{})[kw]=r.get(k)
+for k,row in tab.items(): print(k,row)
+PY

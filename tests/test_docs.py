@@ -41,3 +41,26 @@ def test_the_bench_file_the_blocks_quote_is_a_contract_line_of_this_tree():
     assert "frac_of_blend" in pl and "blend_ceiling_GBps" in pl
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and isinstance(cb["host_cpus"], int) and cb["threads"] == cb["cores"] and "range_GBps" in cb
+
+
+def test_every_c_identifier_the_documents_name_is_declared_in_the_headers():
+    """DESIGN.md / INTEGRATION.md / README.md talk about the C ABI by name; a ``ggq_*`` identifier in them that include/*.h does not declare (an entry point
+    deleted rounds ago, a typo) fails here (Weak #8: DESIGN.md listed ggq_dequant_batch after ABI 10 had removed it)."""
+    import re
+    declared = set()
+    for h in ("ggq.h", "ggq_gguf.h"):
+        declared |= set(re.findall(r"\bggq_[a-z0-9_]+\b", open(os.path.join(ROOT, "include", h)).read()))
+    # names that are not C identifiers of the ABI: the python package's own module / file / op names, build artefacts, lab tools
+    known_other = {"ggq_pkg", "ggq_hip", "ggq_fast", "ggq_capi", "ggq_gguf", "ggq_linear", "ggq_overlap", "ggq_pyfast", "ggq_device", "ggq_mfma", "ggq_mfma16", "ggq_gemm",
+                   "ggq_host", "ggq_oracle", "ggq_oracle_simd", "ggq_microbench", "ggq_lab_engine", "ggq_stream", "ggq_scratch", "ggq_build_", "ggq_refpkg",
+                   "ggq_gemm64", "ggq_reference_dequant"}
+    bad = {}
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for name in set(re.findall(r"\bggq_[a-z0-9_]+\b", text)):
+            if name in declared or name in known_other or name.rstrip("_") in known_other:
+                continue
+            if re.search(r"lib" + name + r"\b|" + name + r"\.(?:hip|hpp|h|c|py|so)\b|_" + name + r"\b", text):     # a file name (libggq_hip.so, ggq_capi.hip, _ggq_fast)
+                continue
+            bad.setdefault(doc, []).append(name)
+    assert not bad, f"identifiers the headers do not declare: {bad}"

@@ -288,31 +288,11 @@ def test_upload_argument_checks_without_a_gpu(pkg, gf, tmp_path):
 
 # ---------------------------------------------------------------- the reference's loader.py, run verbatim
 
-class _RefField:
-    """What loader.py reads off a gguf.ReaderField: .types, and the value through .parts[.data[i]] (loader.py:16-49)."""
-
-    def __init__(self, vt, field):
-        self.types = [vt(t) for t in field.types]
-        values = field.value if isinstance(field.value, tuple) else (field.value,)
-        if field.types[-1] == STRING:
-            self.parts = [np.frombuffer(v.encode("utf-8"), dtype=np.uint8) for v in values]
-        else:
-            self.parts = [np.array([v]) for v in values]
-        self.data = list(range(len(self.parts)))
-
-
-class _RefTensor:
-    def __init__(self, Q, t):
-        self.name, self.tensor_type, self.shape = t.name, t.tensor_type, np.array(t.shape, dtype=np.uint64)
-        raw = t.data.numpy()
-        self.data = raw.view(np.float32) if t.tensor_type == Q.F32 else raw.view(np.float16) if t.tensor_type == Q.F16 else raw
-
-
 def _reference_loader(pkg, monkeypatch):
     """loader.py of /root/reference executed from its own source, with the two things it needs from outside stubbed: `comfy`
-    (test_host._fake_comfy) and `gguf` -- the enum / sizes stub of oracle/reference.py plus a GGUFReader that hands out OUR
-    parser's view of the file in gguf-py's attribute layout.  So the container parsing is not what this pins; everything the
-    loader does with it is."""
+    (test_host._fake_comfy) and `gguf` -- the enum / sizes stub of oracle/reference.py plus, as its GGUFReader, the PRODUCT's adapter
+    (comfyui-gguf_amd/gguf_adapter.py: our parser's view of the file in gguf-py's attribute layout, what install(native_reader=True) puts under the
+    reference's loader).  So the container parsing is not what this pins; everything the loader does with it is."""
     import enum
     import importlib.util
     import sys
@@ -325,17 +305,8 @@ def _reference_loader(pkg, monkeypatch):
     vt = enum.IntEnum("GGUFValueType", dict(UINT8=0, INT8=1, UINT16=2, INT16=3, UINT32=4, INT32=5, FLOAT32=6, BOOL=7, STRING=8, ARRAY=9,
                                             UINT64=10, INT64=11, FLOAT64=12))
 
-    class GGUFReader:
-        def __init__(self, path):
-            self._f = pkg.gguf_file.GGUFFile(str(path))
-            self.tensors = [_RefTensor(Q, t) for t in self._f.tensors]
-
-        def get_field(self, key):
-            f = self._f.get_field(key)
-            return None if f is None else _RefField(vt, f)
-
     monkeypatch.setattr(stub, "GGUFValueType", vt, raising=False)
-    monkeypatch.setattr(stub, "GGUFReader", GGUFReader, raising=False)
+    monkeypatch.setattr(stub, "GGUFReader", pkg.gguf_adapter.make_reader(stub), raising=False)
     for k, v in _fake_comfy().items():
         monkeypatch.setitem(sys.modules, k, v)
     root = types.ModuleType("refldr")
@@ -367,8 +338,9 @@ def _same_state_dict(ours, theirs):
         a, b = ours[key], theirs[key]
         ta, tb = getattr(a, "tensor_type", None), getattr(b, "tensor_type", None)        # None: a plain (dequantized) tensor
         assert (None if ta is None else int(ta)) == (None if tb is None else int(tb)), key
-        assert tuple(a.shape) == tuple(b.shape) and a.dtype == b.dtype and tuple(a.size()) == tuple(b.size()), key
-        assert torch.equal(a.as_subclass(torch.Tensor), b.as_subclass(torch.Tensor)), key
+        assert tuple(a.shape) == tuple(b.shape) and a.dtype == b.dtype and a.numel() == b.numel(), key
+        # (the packed bytes of a quantized tensor: gguf-py -- and the adapter -- hand them out as (rows, bytes per row), this package's loader flat)
+        assert torch.equal(a.as_subclass(torch.Tensor).reshape(-1), b.as_subclass(torch.Tensor).reshape(-1)), key
         assert bool(getattr(a, "is_largest_weight", False)) == bool(getattr(b, "is_largest_weight", False)), key
 
 
@@ -458,6 +430,45 @@ def test_loader_equals_the_reference_loader_run_live(pkg, tmp_path, monkeypatch)
     assert ours.get_orig_shape(a, pre + "x.conv.weight") == ref.get_orig_shape(b, pre + "x.conv.weight") == torch.Size((2, 3, 32))
     assert ours.get_orig_shape(a, "nope") is ref.get_orig_shape(b, "nope") is None
     a.close()
+
+
+@pytest.mark.filterwarnings("ignore::DeprecationWarning")
+@pytest.mark.skipif(not os.path.isfile("/root/reference/loader.py"), reason="/root/reference not present (GPU box)")
+def test_install_native_reader_puts_the_adapter_under_the_reference_loader(pkg, tmp_path, monkeypatch):
+    """install(native_reader=True) (Next #6): the reference's verbatim gguf_sd_loader, with nothing but the name `gguf` in its module rebound,
+    reads the mixed fixture files through the native parser and returns what this package's own loader returns -- keys, order, types, logical shapes,
+    dtypes, bytes, largest-weight mark, architecture -- and uninstall() puts the real module back.  The real `gguf` here is a stub whose GGUFReader
+    RAISES: the state dicts can only have come through the adapter."""
+    import sys
+    ref = _reference_loader(pkg, monkeypatch)
+    stub = sys.modules["gguf"]
+
+    def no_reader(path):
+        raise AssertionError("gguf.GGUFReader was called: the native reader is not in place")
+    monkeypatch.setattr(stub, "GGUFReader", no_reader, raising=False)
+    rd, ro = sys.modules["refldr.dequant"], sys.modules["refldr.ops"]
+    files = _loader_case_files(pkg, tmp_path)
+    with pytest.raises(ValueError):
+        pkg.install.install(rd, ro, native_reader=True)                     # needs ref_loader
+    assert rd.dequantize_tensor.__module__ == "refldr.dequant"              # ... and left nothing patched behind
+    pkg.install.install(rd, ro, ref, native_reader=True, exact=True)
+    try:
+        assert type(ref.gguf).__name__ == "GGUFModuleProxy" and ref.gguf.GGMLQuantizationType is stub.GGMLQuantizationType
+        for label in ("flux", "sd3", "t5", "plain"):
+            for kw in (dict(return_arch=True), dict(handle_prefix=None), dict(is_text_model=True, return_arch=True)):
+                (got, e1), (want, e2) = _outcome(ref.gguf_sd_loader, files[label], **kw), _outcome(pkg.loader.gguf_sd_loader, files[label], **kw)
+                assert (e1 is None) == (e2 is None) and type(e1) is type(e2), (label, kw, e1, e2)
+                if e1 is None:
+                    if kw.get("return_arch"):
+                        assert got[1] == want[1]
+                        got, want = got[0], want[0]
+                    _same_state_dict(want, got)
+        assert "native_reader=True" in pkg.install.describe(rd)
+    finally:
+        pkg.install.uninstall(rd)
+    assert ref.gguf is stub
+    with pytest.raises(AssertionError):
+        ref.gguf_sd_loader(files["flux"])
 
 
 def sys_modules_reader(path):

@@ -436,15 +436,18 @@ def test_autograd_through_the_default_install(mods, pkg, dev):
             out[name] = xi.grad
         assert torch.equal(out["exact"], out["default"]), m
     with H.Installed(pkg, mods, fast=True), torch.no_grad():
-        x = torch.randn(2, 512, device=dev, dtype=torch.float16)
         calls = []
-        real = pkg.fused._small_call or (pkg.fused._bind() or pkg.fused._small_call)
-        pkg.fused._small_call = lambda *a: (calls.append(1), real(*a))[1]
+        if pkg.fused._small_call is None:
+            pkg.fused._bind()
+        real_small, real_mfma = pkg.fused._small_call, pkg.fused._mfma_call
+        pkg.fused._small_call = lambda *a: (calls.append("small"), real_small(*a))[1]
+        pkg.fused._mfma_call = lambda *a: (calls.append("mfma"), real_mfma(*a))[1]
         try:
-            lin(x)
+            for m in (1, 2, 40):
+                lin(torch.randn(m, 512, device=dev, dtype=torch.float16))
         finally:
-            pkg.fused._small_call = real
-        assert calls, "under no_grad the default install still runs the fused kernel"
+            pkg.fused._small_call, pkg.fused._mfma_call = real_small, real_mfma
+        assert calls == ["small", "mfma", "mfma"], f"under no_grad the default install runs the fused kernels (one row: the GEMV; more: the MFMA kernels), got {calls}"
 
 
 def test_torch_compile_inductor_through_reference_linear(mods, pkg, dev):

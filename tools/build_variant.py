@@ -21,19 +21,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _objects_without_defines(nat, cache):
-    """The translation units the -D flags of an A/B build do not reach (GGUF reader, fused linears, side-stream prefetch), compiled once per
+def _objects_without_defines(nat, cache, skip=0):
+    """The translation units the -D flags of an A/B build do not reach (all but nat.SOURCES[skip]), compiled once per
     source state into ``cache`` and shared by every variant."""
     import hashlib
     os.makedirs(cache, exist_ok=True)
     h = hashlib.sha256(" ".join(nat.HIPCC_FLAGS).encode())
-    for path in nat.SOURCES[1:] + nat.HEADERS:
+    others = [p for i, p in enumerate(nat.SOURCES) if i != skip]
+    for path in others + nat.HEADERS:
         with open(path, "rb") as f:
             h.update(f.read())
     tag = h.hexdigest()[:12]
     objs, jobs = [], []
     flags = [f for f in nat.HIPCC_FLAGS if f != "-shared"]
-    for src in nat.SOURCES[1:]:
+    for src in others:
         obj = os.path.join(cache, f"{os.path.splitext(os.path.basename(src))[0]}.{tag}.o")
         objs.append(obj)
         if not os.path.exists(obj):
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("-o", "--out", required=True)
     ap.add_argument("--all-sources", action="store_true", help="pass the -D flags to every translation unit (default: to csrc/ggq_capi.hip, which holds "
                                                                "every dequant kernel and its launch geometry; the other three are compiled once and shared)")
+    ap.add_argument("--unit", default="ggq_capi.hip", help="the translation unit the -D flags go to (ggq_capi.hip: the dequant kernels; ggq_linear.hip: the fused linears)")
     args, defines = ap.parse_known_args()
     bad = [d for d in defines if not d.startswith("-D")]
     if bad:
@@ -64,10 +66,13 @@ def main():
         if args.all_sources:
             cmd = [nat.hipcc_path()] + nat.HIPCC_FLAGS + defines + stamp + ["-save-temps=obj", "-o", lib] + nat.SOURCES
         else:
-            shared = _objects_without_defines(nat, os.path.join(os.path.dirname(out), ".obj"))
-            obj = os.path.join(tmp, "ggq_capi.o")
+            unit = [i for i, p in enumerate(nat.SOURCES) if os.path.basename(p) == args.unit]
+            if not unit:
+                ap.error(f"--unit: one of {[os.path.basename(p) for p in nat.SOURCES]}")
+            shared = _objects_without_defines(nat, os.path.join(os.path.dirname(out), ".obj"), unit[0])
+            obj = os.path.join(tmp, "unit.o")
             compile_flags = [f for f in nat.HIPCC_FLAGS if f != "-shared"]
-            proc = subprocess.run([nat.hipcc_path()] + compile_flags + defines + stamp + ["-save-temps=obj", "-c", "-o", obj, nat.SOURCES[0]], cwd=tmp, capture_output=True, text=True)
+            proc = subprocess.run([nat.hipcc_path()] + compile_flags + defines + stamp + ["-save-temps=obj", "-c", "-o", obj, nat.SOURCES[unit[0]]], cwd=tmp, capture_output=True, text=True)
             if proc.returncode:
                 sys.exit(proc.stderr[-4000:])
             cmd = [nat.hipcc_path()] + nat.HIPCC_FLAGS + ["-o", lib, obj] + shared
