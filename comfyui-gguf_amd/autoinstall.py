@@ -33,7 +33,15 @@ def _install_over(ops_mod):
         return
     try:
         from . import install as inst
-        inst.install(deq, ops_mod, sys.modules.get(pkg + ".loader"))
+        loader = sys.modules.get(pkg + ".loader")
+        if loader is None and inst._env_flag("GGQ_NATIVE_READER"):
+            # the hook fires right after <package>.ops has executed -- before nodes.py gets to `from .loader import ...`.  The option rebinds a name inside
+            # the loader module, so import it now (it only needs .ops and .dequant, both executed); a checkout without loader.py keeps gguf-py's reader.
+            try:
+                loader = importlib.import_module(pkg + ".loader")
+            except Exception:                              # noqa: BLE001
+                log.warning("comfyui-gguf_amd: GGQ_NATIVE_READER=1 but %s.loader cannot be imported; gguf-py's GGUFReader stays", pkg)
+        inst.install(deq, ops_mod, loader, native_reader=None if loader is not None else False)
         _state["installed"] = pkg
         log.info("comfyui-gguf_amd: MI355X HIP dequant path installed over %s (dequantize, dequantize_tensor%s)", pkg, inst.describe(deq))
     except Exception:                                      # noqa: BLE001 -- see docstring

@@ -94,39 +94,31 @@ GGQ_TUNE(FmtQ3_K,    8,  false, 1,    0);
 GGQ_TUNE(FmtQ6_K,    8,  false, 1,    6);
 #undef GGQ_TUNE
 
-// The bf16 / fp32 arithmetic modes (dequant_dtype of the Advanced loader) carry 2-4x the VALU work per element; with only
-// two chunks per thread the coop teams then lose 1-7 % on every format but the two with the lightest arithmetic per
-// packed byte (bench.py per-mode table, solo vs coop builds on one box): those modes run the solo shape.
+// Team shape per (format, arithmetic, output) -- the table after the two-box pruning of round 6 (Next #7).
+// The GENERAL RULE: workgroup teams for the stock fp16 arithmetic and for every fp32 OUTPUT (one decode per chunk, halves swapped inside lane pairs: ggq_device.hpp
+// pair_f32), one-wave teams for the bf16 / fp32 arithmetic modes of the Advanced loader (2-4x the VALU work per element: with only two chunks per thread the workgroup teams
+// lose 3-8 % there).  An EXCEPTION stays listed only if an all-workgroup-team build against an all-one-wave-team build (tools/mode_table.py --arith, two alternations each)
+// says so by >= 2 % with the same sign on TWO different boxes (tools/mode_prune.py -> profiles/r06_mode_table_two_boxes.json).  Seven of the twelve of round 5 did:
+//   Q8_0 in every arithmetic mode: workgroup teams +2.4...+9.8 % (the lightest arithmetic per packed byte);
+//   Q4_1, Q5_1 in fp32 arithmetic with 2-byte outputs: workgroup teams +2.3...+6.7 %;
+//   Q4_K with bf16 output (the production case: FLUX computes in bf16): one-wave teams +3.8 / +4.4 %;
+// one is new -- Q2_K bf16 arithmetic -> fp32 output: one-wave teams +3.5 / +5.6 % -- and five are gone: bf16 output of Q2_K / Q5_K / IQ4_NL / IQ4_XS in one-wave teams
+// (-0.3...+2.8 %: sign flips or < 2 % on a box), Q5_1 bf16 -> bf16 in workgroup teams (+0.7 / +1.9 %), and Q4_1's "every mode" entry with its two bf16-arithmetic overrides
+// (now just the fp32-arithmetic cells).
 #ifdef GGQ_COOP_ALL_MODES     /* A/B builds only: the workgroup teams in every arithmetic mode and for every output dtype */
 template <class F> struct CoopInAllModes { static constexpr bool V = true; };
 #else
 template <class F> struct CoopInAllModes { static constexpr bool V = false; };
-template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };     // +7...12 % in every mode
-template <> struct CoopInAllModes<FmtQ4_1> { static constexpr bool V = true; };     // +4 % fp32 arithmetic, level in bf16
+template <> struct CoopInAllModes<FmtQ8_0> { static constexpr bool V = true; };
 #endif
-// ... and so does the bf16 output cast (1.5 more conversions per element, the production case: FLUX computes in bf16) for the
-// formats with the heavier decode.  Same-box alternation of two builds over all formats and output dtypes
-// (tools/mode_table.py, profiles/r01_mode_table_coop_vs_solo_cast_outputs.json), solo vs coop with bf16 output: Q5_K +5.5 %,
-// Q4_K +4.0 %, Q2_K +4.0 %, IQ4_NL +3.8 %, IQ4_XS +3.0 %; level for Q4_0 / Q5_0; Q4_1 -2.6 %, Q5_1 -2.1 %, Q8_0 -4.2 % (stay coop).
-// fp32 output keeps the coop shape everywhere (solo: -1...-9 %, level for Q5_0 / Q5_K / IQ4_XS).
 #if defined(GGQ_SOLO_CAST_OUT)      /* A/B builds only: one-wave teams whenever the output is not fp16 */
 template <class F, int OUT> struct CoopForOut { static constexpr bool V = OUT == OUT_F16; };
 #elif defined(GGQ_COOP_ALL_MODES)
 template <class F, int OUT> struct CoopForOut { static constexpr bool V = true; };
 #else
 template <class F, int OUT> struct CoopForOut { static constexpr bool V = true; };
-template <> struct CoopForOut<FmtQ2_K, OUT_BF16> { static constexpr bool V = false; };
 template <> struct CoopForOut<FmtQ4_K, OUT_BF16> { static constexpr bool V = false; };
-template <> struct CoopForOut<FmtQ5_K, OUT_BF16> { static constexpr bool V = false; };
-template <> struct CoopForOut<FmtIQ4_NL, OUT_BF16> { static constexpr bool V = false; };
-template <> struct CoopForOut<FmtIQ4_XS, OUT_BF16> { static constexpr bool V = false; };
 #endif
-// The rule: workgroup teams for the fp16 arithmetic (minus the bf16-output exceptions), one-wave teams for the other arithmetic modes except Q8_0 / Q4_1;
-// fp32 OUTPUT always takes the workgroup teams (round 5: with one decode per chunk and the halves swapped inside lane pairs -- ggq_device.hpp pair_f32 --
-// the workgroup shape wins or is level in every arithmetic mode: mean of the 36 fp32-output cells 6147 GB/s against 6006 for the round-4 table,
-// profiles/r05_mode_table_f32out_pairing_and_teams.json; that one rule replaces seven per-cell exceptions).  The cells where an all-coop against an all-solo
-// build, alternated twice on one box over all 12 x 9 cells (profiles/r01_mode_table_all_coop_vs_all_solo.json), says otherwise by more than 1.5 % in both
-// alternations stay listed:
 template <class F, int ARITH, int OUT> struct UseCoop {
 #ifdef GGQ_F32_TEAMS_R4     /* A/B builds only: fp32 output follows the arithmetic's team shape, as in rounds 1-4 (minus that table's per-cell exceptions) */
     static constexpr bool V = (ARITH == AR_F16 || CoopInAllModes<F>::V) && CoopForOut<F, OUT>::V;
@@ -136,11 +128,12 @@ template <class F, int ARITH, int OUT> struct UseCoop {
 };
 #if !defined(GGQ_SOLO_CAST_OUT) && !defined(GGQ_COOP_ALL_MODES)
 #define GGQ_TEAM(F, AR, OUT_, COOP_) template <> struct UseCoop<F, AR, OUT_> { static constexpr bool V = COOP_; }
-GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_F16, false);     // coop -4.1 %  (bf16 arithmetic: -1.1 % with bf16 output, taken along)
-GGQ_TEAM(FmtQ4_1, AR_BF16, OUT_BF16, false);
-GGQ_TEAM(FmtQ5_1, AR_BF16, OUT_BF16, true);     // coop +1.8 %
-GGQ_TEAM(FmtQ5_1, AR_F32, OUT_F16, true);       //      +3.6 %
-GGQ_TEAM(FmtQ5_1, AR_F32, OUT_BF16, true);      //      +4.5 %
+//       format   arithmetic  output   workgroup teams?     all-workgroup / all-one-wave build on box A, box B
+GGQ_TEAM(FmtQ4_1, AR_F32,  OUT_F16,  true);              // 1.046  1.039
+GGQ_TEAM(FmtQ4_1, AR_F32,  OUT_BF16, true);              // 1.037  1.035
+GGQ_TEAM(FmtQ5_1, AR_F32,  OUT_F16,  true);              // 1.067  1.030
+GGQ_TEAM(FmtQ5_1, AR_F32,  OUT_BF16, true);              // 1.058  1.023
+GGQ_TEAM(FmtQ2_K, AR_BF16, OUT_F32,  false);             // 0.966  0.947
 #undef GGQ_TEAM
 #endif
 // fp32 output writes twice the bytes per element: a workgroup team's 4096 elements would be FOUR 1-KiB store rows per wave, and a pure fill already runs

@@ -131,6 +131,19 @@ AUTO_MAX_ROWS = 256      # rows of x up to which a fused MFMA shape beats dequan
 # one unpack + hipBLASLt: FLUX's 21504 x 3072 `linear1` at 192 / 256 rows runs 79.6 / 78.3 us fused against 63.2 / 68.6 us unpack + F.linear, while 12288 x 3072 at 256 rows
 # (52.9 vs 54.6) and everything smaller still wins or is level (profiles/r05_mfma_tile_choice_96_to_256_rows.json).  21504 x 192 = 4.1 M declines, 12288 x 256 = 3.1 M stays.
 AUTO_MAX_ROWS_TIMES_OUT = 3_600_000
+# ... and the 32-element-block formats (Q4_0 ... Q8_0, IQ4_NL) altogether above this many rows of x: at 256 rows SD3.5-large's Q5_0 layers (2432 columns) run 1.7-2.3x SLOWER fused than
+# unpack + hipBLASLt (66.9 vs 39.7 us at 7296 x 2432, 124.8 vs 53.2 at 14592 x 2432; profiles/r06_mid_m_sweep.json, threshold sweep profiles/r06_legacy_formats_row_threshold.json)
+AUTO_MAX_ROWS_LEGACY_BLOCKS = 128
+# ... and the two 5-bit ones among them (Q5_0, Q5_1: a fifth-bit plane to merge per chunk) already above 64: SD3.5's 7296 x 2432 Q5_0 at 32 / 64 / 96 / 128 rows runs 17.8 / 21.7 / 35.3 / 36.1 us
+# fused against 33.4 / 30.7 / 31.8 / 32.9 unpack + hipBLASLt (the same file); Q8_0 still wins at 128 rows on 4096- and 3072-row weights (21.6 vs 36.9, 46.6 vs 70.7)
+AUTO_MAX_ROWS_LEGACY_5BIT = 64
+_LEGACY_5BIT = (6, 7)          # ggml type ids of Q5_0, Q5_1
+
+
+def _legacy_row_limit(qid, block_size):
+    if block_size != 32:
+        return AUTO_MAX_ROWS
+    return AUTO_MAX_ROWS_LEGACY_5BIT if qid in _LEGACY_5BIT else AUTO_MAX_ROWS_LEGACY_BLOCKS
 
 
 def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None, auto_max_rows=AUTO_MAX_ROWS):
@@ -147,9 +160,11 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
     if tile_rows not in (0, 16, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
         raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 16, 32, 64, 128 or 256 (the shared-tile kernel: rows % 8 == 0, cols % 256 == 0)")
-    if tile_rows == 0 and auto_max_rows is not None and (m > auto_max_rows or (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)):
+    if tile_rows == 0 and auto_max_rows is not None and (m > auto_max_rows or (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)
+                                                          or m > _legacy_row_limit(qid, _HIP_TABLE[_qtype_key(qid)][1])):
         raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x on {rows} output columns -- dequantize + F.linear is the faster path there "
-                             f"(above {auto_max_rows} rows, or above 128 rows with rows x columns > {AUTO_MAX_ROWS_TIMES_OUT}); pass tile_rows= to force a fused shape")
+                             f"(above {auto_max_rows} rows; above 128 rows with rows x columns > {AUTO_MAX_ROWS_TIMES_OUT}; above {AUTO_MAX_ROWS_LEGACY_BLOCKS} rows for the "
+                             f"32-element-block formats, {AUTO_MAX_ROWS_LEGACY_5BIT} for Q5_0 / Q5_1); pass tile_rows= to force a fused shape")
     if _mfma_call is None:
         _bind()
     return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)
@@ -280,7 +295,8 @@ def linear_traced(layer, x, small_m, mfma_max_m):
     mfma = False
     if not small:
         k_ok = cols % 256 == 0 or (block_size == 32 and cols % 64 == 0)
-        mfma = (x.dtype in (_F16, _BF16) and k_ok and m <= mfma_max_m and m <= AUTO_MAX_ROWS and not (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT))
+        mfma = (x.dtype in (_F16, _BF16) and k_ok and m <= mfma_max_m and m <= AUTO_MAX_ROWS and not (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)
+                and m <= _legacy_row_limit(qid, block_size))
         if not mfma:
             return None
     if weight.device != x.device:

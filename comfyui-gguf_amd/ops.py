@@ -105,18 +105,11 @@ class GGMLLinear(GGMLLayer):
     fuse_mfma_max_m = 0                            # opt-in: inputs of up to this many rows go through fused.linear_mfma
 
     def forward(self, input):
-        if self.fuse_small_m and is_quantized(self.weight) and input.numel() <= 4 * input.shape[-1]:
-            from .fused import linear_small
+        if (self.fuse_small_m or self.fuse_mfma_max_m) and is_quantized(self.weight):
+            from .fused import linear_auto                 # the policy of install()'s default (fused.py): GEMV / 16-row / 32-row MFMA kernel by rows of x
             from .dequant import GGQUnsupported
             try:
-                return linear_small(input, self.weight, self.bias, self.dequant_dtype, weight_to=input.device)
-            except GGQUnsupported:
-                pass
-        if self.fuse_mfma_max_m and is_quantized(self.weight) and input.numel() <= self.fuse_mfma_max_m * input.shape[-1]:
-            from .fused import linear_mfma
-            from .dequant import GGQUnsupported
-            try:
-                return linear_mfma(input, self.weight, self.bias, self.dequant_dtype, weight_to=input.device)
+                return linear_auto(input, self.weight, self.bias, self.dequant_dtype, input.device, self.fuse_small_m, self.fuse_mfma_max_m)
             except GGQUnsupported:
                 pass
         if not self.is_ggml_quantized():

@@ -16,7 +16,13 @@ pytestmark = pytest.mark.skipif(not reference.available(), reason="reference sou
 
 @pytest.fixture(scope="module")
 def rig(pkg):
-    mods = reference.load_reference_package(name="ggq_refpkg_trace")
+    import sys
+    added, missing = [], object()
+
+    def setitem(mapping, key, value):                     # remember what sys.modules held: everything is put back at teardown (the drop-in tests scan sys.modules)
+        added.append((mapping, key, mapping.get(key, missing)))
+        mapping[key] = value
+    mods = reference.load_reference_package(name="ggq_refpkg_trace", setitem=setitem)
     D, F = pkg.dequant, pkg.fused
     if D._dequantize_op is None or F._linear_small_op is None:
         pytest.skip("torch without torch.library.custom_op")
@@ -31,6 +37,11 @@ def rig(pkg):
     F._TRACE_ANY_DEVICE = D._TRACE_ANY_DEVICE = True
     yield mods
     F._TRACE_ANY_DEVICE, D._TRACE_ANY_DEVICE = old
+    for mapping, key, prev in reversed(added):
+        if prev is missing:
+            mapping.pop(key, None)
+        else:
+            mapping[key] = prev
 
 
 def _explain(fn, *args):

@@ -168,3 +168,28 @@ def test_ggq_fast_switch_turns_on_the_no_vram_opt_ins(custom_nodes, monkeypatch,
     assert "fused_small_m=True" in caplog.text and "fused_mfma=256" in caplog.text and "gather_embedding" not in caplog.text
     amd_mod.install.uninstall(rd)
     assert not hasattr(ro.GGMLOps.Linear.forward_ggml_cast_weights, "__wrapped__")
+
+
+@pytest.mark.parametrize("with_loader", [True, False], ids=["loader.py present", "checkout without loader.py"])
+def test_ggq_native_reader_under_the_drop_in(custom_nodes, monkeypatch, caplog, with_loader):
+    """GGQ_NATIVE_READER=1 (round 6): the hook fires right after <package>.ops has executed -- before nodes.py reaches `from .loader import ...` -- so it imports
+    the loader module itself and rebinds the name `gguf` inside it to the proxy whose GGUFReader is the native adapter; a checkout without loader.py keeps working
+    (one warning, everything else installed)."""
+    ref_dir, amd_dir = custom_nodes
+    if with_loader:
+        shutil.copy(os.path.join(reference.REFERENCE_DIR, "loader.py"), os.path.join(ref_dir, "loader.py"))
+    monkeypatch.setenv("GGQ_NATIVE_READER", "1")
+    amd_mod = _comfy_load_custom_node(amd_dir)                               # this package first: the hook is armed, the reference arrives later
+    with caplog.at_level(logging.INFO, logger="comfyui-gguf_amd"):
+        ref_mod = _comfy_load_custom_node(ref_dir)
+    rd = sys.modules[ref_mod.__name__ + ".dequant"]
+    assert amd_mod.autoinstall._state["installed"] == ref_mod.__name__ and hasattr(rd.dequantize_tensor, "__wrapped__")
+    if with_loader:
+        ldr = sys.modules[ref_mod.__name__ + ".loader"]
+        assert type(ldr.gguf).__name__ == "GGUFModuleProxy" and issubclass(ldr.gguf.GGUFReader, amd_mod.gguf_adapter.GGUFReaderAdapter)
+        assert ldr.gguf.GGMLQuantizationType is sys.modules["gguf"].GGMLQuantizationType and "native_reader=True" in caplog.text
+        amd_mod.install.uninstall(rd)
+        assert ldr.gguf is sys.modules["gguf"]
+    else:
+        assert "GGUFReader stays" in caplog.text and "native_reader=True" not in amd_mod.install.describe(rd)
+        amd_mod.install.uninstall(rd)

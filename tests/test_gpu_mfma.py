@@ -67,7 +67,12 @@ def test_auto_dispatch_reaches_the_shared_tile_kernel(pkg, name):
     assert not torch.equal(ksplit, tile)                                                    # (the K-split kernel sums in another order: the two are distinguishable)
     small = pkg.fused.linear_mfma(x[:1024], w, auto_max_rows=None)                          # 4 x 9 tiles: the library stays with the K-split kernel
     assert torch.equal(small, pkg.fused.linear_mfma(x[:1024], w, tile_rows=128)) and not torch.equal(small, tile[:1024])
-    assert torch.equal(pkg.fused.linear_mfma(x[:200], w), pkg.fused.linear_mfma(x[:200], w, tile_rows=64))   # <= 256 rows: served by default
+    if pkg.qtypes.block_geometry(q)[0] == 32:                                                # 32-element-block formats: the auto policy serves up to 128 rows of x (round 6)
+        with pytest.raises(pkg.dequant.GGQUnsupported):
+            pkg.fused.linear_mfma(x[:200], w)
+        assert torch.equal(pkg.fused.linear_mfma(x[:100], w), pkg.fused.linear_mfma(x[:100], w, tile_rows=64))
+    else:
+        assert torch.equal(pkg.fused.linear_mfma(x[:200], w), pkg.fused.linear_mfma(x[:200], w, tile_rows=64))   # <= 256 rows: served by default
     # an output view that is not 16-byte aligned cannot take the shared-tile epilogue's vector stores: the C entry point says so
     import ctypes
     L = pkg._native.lib()

@@ -5,10 +5,10 @@ README.md lives inside a generated block
 
 whose text this script derives from the committed measurement files and nothing else:
 
-    profiles/r05_bench_n1.json                              one `python bench.py` line (the newest profiles/r*_bench_n1.json unless given)
+    profiles/rNN_bench_n1.json                              one `python bench.py` line (the newest profiles/r*_bench_n1.json unless given)
     profiles/pmc_traffic.json                               PMC bytes per launch
-    profiles/r05_flux_forward_emulation_token_sweep.json    tools/token_sweep.py (and r05_forward_emulation_token_sweep_sd35.json / _t5.json)
-    profiles/r05_fused_error.json                           tools/fused_error.py
+    profiles/rNN_flux_forward_emulation_token_sweep.json    tools/token_sweep.py (and rNN_forward_emulation_token_sweep_sd35.json / _t5.json), newest round
+    profiles/rNN_fused_error.json                           tools/fused_error.py, newest round
 
     python tools/design_table.py [bench.json]            # prints every block
     python tools/design_table.py --write                 # rewrites the blocks in the three documents
@@ -148,16 +148,43 @@ def token_table(ts, src):
 
 def fused_error_block(fe, src):
     s = fe["summary"]
+    kernels = {}
+    for c in fe["cases"]:
+        if c.get("fused"):
+            kernels[c["fused"]] = kernels.get(c["fused"], 0) + 1
+    by_kernel = ", ".join(f"`{k}` {v}" for k, v in sorted(kernels.items()))
+    dec = {}
+    for c in fe["cases"]:
+        if not c.get("fused"):
+            dec.setdefault(f"{c['qtype']} {c['rows']}×{c['cols']}", set()).add(c["m"])
+    declined = "; ".join(f"{k} at {'/'.join(str(m) for m in sorted(v))} rows" for k, v in sorted(dec.items())) or "none"
     return "\n".join([
         f"Source: `{src}` (`tools/fused_error.py`, {fe.get('device', 'MI355X')}, torch {fe.get('torch', '?')}): {s['cases']} cases = every distinct linear shape of FLUX.1-dev / SD3.5-large / T5-xxl × "
         f"{{1, 4, 64, 256}} rows × {{bf16, fp16}}, error against an fp64 product on the ORACLE's weights, relative to RMS(exact).",
-        f"- fused kernel ran in {s['fused_ran']} cases; the other {s['declined']} are declined and keep unpack + `F.linear`: rows wider than `ggq_linear_small`'s LDS staging at ≤ 4 rows (FLUX's 12288- and "
-        f"15360-column layers, which never see so few rows), and 256 rows of x on the tallest weights (≥ 14592 output columns), which the auto policy hands back because unpack + hipBLASLt is faster there "
-        f"(`fused.AUTO_MAX_ROWS_TIMES_OUT`);",
+        f"- fused kernel ran in {s['fused_ran']} cases ({by_kernel}); the other {s['declined']} are declined by the auto policy and keep unpack + `F.linear`, which is faster there: {declined};",
         f"- worst RMS-error ratio fused ÷ default: **{s['worst_rms_ratio_fused_over_default']:.7f}**; worst max-error ratio: **{s['worst_max_ratio_fused_over_default']:.4f}**; "
         f"max error never above the default path's by more than {max(0.0, s['worst_max_excess_in_output_ulps']):.2f} output rounding steps;",
         f"- outputs bit-identical to the default path's: ≥ {100 * s['min_same_bits_share']:.2f} % in every case; run-to-run: fused non-deterministic in {s['fused_nondeterministic']} cases, default in {s['default_nondeterministic']};",
         f"- verdict of the rule in `tools/fused_error.py` (RMS within 2 %, max within one output rounding step, deterministic): **fused_no_worse = {s['fused_no_worse']}**."])
+
+
+def fused_roofline(d, src):
+    """The fused dequantize + linear kernels under the bench's own clock (workloads.fused_small_m / fused_mfma of the default run): packed-read roofline per m."""
+    w = d["workloads"]
+    rows = [f"Source: `{src}` `workloads.fused_small_m` / `workloads.fused_mfma` ({w['fused_mfma']['how']}).", "",
+            "| rows of x | kernel(s) | layers fused (declined) | ms per pass · µs per layer | packed GB/s read | fraction of 8 TB/s | TFLOP/s |", "|---|---|---|---|---|---|---|"]
+    for group in ("fused_small_m", "fused_mfma"):
+        for k, v in w[group].items():
+            if k == "how":
+                continue
+            r = v["roofline"]
+            rows.append(f"| {k[2:]} | `{r['kernel']}` | {v['layers_fused']} ({v['layers_declined']}) | {v['ms_per_pass']} · {v['us_per_layer']} | **{r['achieved']:.0f}** | **{r['frac']:.3f}** | {v['TFLOPs']} |")
+    return "\n".join(rows)
+
+
+def newest_profile(suffix):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return files[-1] if files else None
 
 
 def blocks(bench_path=None):
@@ -165,13 +192,15 @@ def blocks(bench_path=None):
     d = load(bench_path)
     tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     out = {"headline-table": headline_table(d, tr, rel(bench_path)), "summary": summary(d, rel(bench_path))}
-    for name, fname in (("token-sweep", "r05_flux_forward_emulation_token_sweep.json"), ("token-sweep-sd35", "r05_forward_emulation_token_sweep_sd35.json"),
-                        ("token-sweep-t5", "r05_forward_emulation_token_sweep_t5.json")):
-        p = os.path.join(ROOT, "profiles", fname)
-        if os.path.exists(p):
+    if "fused_mfma" in d.get("workloads", {}) and "how" in d["workloads"]["fused_mfma"]:
+        out["fused-roofline"] = fused_roofline(d, rel(bench_path))
+    for name, fname in (("token-sweep", "flux_forward_emulation_token_sweep.json"), ("token-sweep-sd35", "forward_emulation_token_sweep_sd35.json"),
+                        ("token-sweep-t5", "forward_emulation_token_sweep_t5.json")):
+        p = newest_profile(fname)
+        if p:
             out[name] = token_table(load(p), rel(p))
-    p = os.path.join(ROOT, "profiles", "r05_fused_error.json")
-    if os.path.exists(p):
+    p = newest_profile("fused_error.json")
+    if p:
         out["fused-error"] = fused_error_block(load(p), rel(p))
     return out
 

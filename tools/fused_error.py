@@ -57,6 +57,19 @@ def measure(pkg, device, ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), models=("fl
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     cases = []
+    # which C entry point the policy really called: the two bindings are wrapped for the duration of the measurement
+    if fused._small_call is None:
+        fused._bind()
+    real_small, real_mfma, ran = fused._small_call, fused._mfma_call, []
+    fused._small_call = lambda *a: (ran.append("ggq_linear_small"), real_small(*a))[1]
+    fused._mfma_call = lambda *a: (ran.append("ggq_linear_mfma"), real_mfma(*a))[1]
+    try:
+        return _measure(pkg, device, ms, dtypes, models, shapes, seed, with_bias, ran, T, F, fused, dq, oracle, gen, cases)
+    finally:
+        fused._small_call, fused._mfma_call = real_small, real_mfma
+
+
+def _measure(pkg, device, ms, dtypes, models, shapes, seed, with_bias, ran, T, F, fused, dq, oracle, gen, cases):
     for si, (model, layer, q, rows, cols) in enumerate(shapes or linear_shapes(pkg, models)):
         bs, ts = pkg.qtypes.block_geometry(q)
         packed = pkg.synth.device_blocks(q, pkg.synth.n_blocks_for(q, rows * cols), device, seed + si)
@@ -77,9 +90,9 @@ def measure(pkg, device, ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), models=("fl
                 # (a) the default path, twice
                 ya = [F.linear(x, dq.dequantize_tensor(w, dtype), bias) for _ in range(2)]
                 # (b) the fused path, twice -- what install(fast) would run for this many rows; None when the kernel declines the shape
+                ran.clear()
                 try:
-                    run = (lambda: fused.linear_small(x, w, bias)) if m <= fused.MAX_ROWS else (lambda: fused.linear_mfma(x, w, bias))
-                    yb = [run() for _ in range(2)]
+                    yb = [fused.linear_auto(x, w, bias) for _ in range(2)]     # the default's own policy (fused.py): GEMV at one row, the MFMA kernels above
                 except dq.GGQUnsupported as e:
                     cases.append({"model": model, "layer": layer, "qtype": q.name, "rows": rows, "cols": cols, "m": m, "dtype": dname,
                                   "fused": None, "declined": str(e)[:80]})
@@ -87,7 +100,7 @@ def measure(pkg, device, ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), models=("fl
                 a_max, a_rms = _stats(ya[0], exact, scale)
                 b_max, b_rms = _stats(yb[0], exact, scale)
                 cases.append({"model": model, "layer": layer, "qtype": q.name, "rows": rows, "cols": cols, "m": m, "dtype": dname,
-                              "fused": "ggq_linear_small" if m <= fused.MAX_ROWS else "ggq_linear_mfma",
+                              "fused": ran[-1],
                               "default_max": a_max, "default_rms": a_rms, "fused_max": b_max, "fused_rms": b_rms,
                               "same_bits_share": float((ya[0] == yb[0]).double().mean()),
                               "default_deterministic": bool(torch.equal(ya[0], ya[1])), "fused_deterministic": bool(torch.equal(yb[0], yb[1]))})
