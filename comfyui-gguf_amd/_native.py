@@ -20,7 +20,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
 HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
 # rounded fp16 multiply and subtract into v_pk_fma_f16 (SURVEY.md section 0 finding 3).
@@ -84,6 +84,8 @@ SYMBOLS = {
     "ggq_overlap_wait": (_int, [_vp, _int, _vp]),
     "ggq_overlap_destroy": (None, [_vp]),
     "ggq_linear_mfma": (_int, [_int, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _int, _int, _vp]),
+    "ggq_linear_mfma_ws": (_int, [_int, _vp, _u32, _u32, _vp, _u32, _vp, _vp, _int, _int, _vp, _u64, _vp]),
+    "ggq_linear_mfma_workspace": (_u64, [_int, _u32, _u32, _u32, _int]),
     "ggq_dequant_rows": (_int, [_int, _vp, _u64, _u32, _vp, _u64, _vp, _int, _int, _vp]),
     # include/ggq_gguf.h
     "ggq_gguf_open": (_int, [ctypes.c_char_p, ctypes.POINTER(_vp)]),
@@ -242,7 +244,8 @@ def fast():
     if getattr(mod, "ABI", None) != L.ggq_abi_version():
         return None                                            # built against another ggq.h: raw function pointers with other signatures
     mod.bind(ctypes.cast(L.ggq_dequant, ctypes.c_void_p).value)
-    mod.bind_linear(ctypes.cast(L.ggq_linear_small, ctypes.c_void_p).value, ctypes.cast(L.ggq_linear_mfma, ctypes.c_void_p).value)
+    mod.bind_linear(ctypes.cast(L.ggq_linear_small, ctypes.c_void_p).value, ctypes.cast(L.ggq_linear_mfma, ctypes.c_void_p).value,
+                    ctypes.cast(L.ggq_linear_mfma_ws, ctypes.c_void_p).value)
     return mod
 
 

@@ -374,7 +374,7 @@ struct ggq_plan {
 
 extern "C" {
 
-int ggq_abi_version(void) { return 10; }
+int ggq_abi_version(void) { return 11; }
 
 #ifndef GGQ_BUILD_ID
 #define GGQ_BUILD_ID "unstamped"

@@ -93,25 +93,45 @@ const LinEntry LINEAR[] = {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- the MFMA kernel (ggq_mfma.hpp): tile = MB*32 rows of x  x  32 output columns; MB picked from m
-typedef hipError_t (*mfma_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, uint32_t, hipStream_t);
+typedef hipError_t (*mfma_fn)(const void*, const void*, const void*, void*, uint32_t, uint32_t, uint32_t, void*, uint64_t, hipStream_t);
 
 // K-split width of the 32-row kernel: a launch parameter since round 6 (rounds 2-5: always 4 waves per workgroup).
 uint32_t mf_waves(uint32_t tiles, uint32_t n_spans, uint32_t slots, uint32_t min_kw, uint32_t max_kw);
 
-template <class F, int OUT, int MB>
-hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+// K split ACROSS workgroups (round 6): a weight with few rows gives the 32-row kernel few workgroups -- FLUX's 3072 x 12288 `mlp.2` is 96 of them, each walking 48 spans,
+// on 256 CUs: 37 us at 64 rows of x where 12288 x 3072 (the same bytes, 384 workgroups) takes 23.  With a caller-provided workspace the launch gets gridDim.z slices of whole
+// spans, every workgroup stores fp32 partial sums of its slice, and splitk_reduce adds them in slice order (deterministic), the bias, and casts.  zs = 1: no split.
+uint32_t mf_splitk(uint32_t workgroups, uint32_t n_spans, uint32_t m, uint32_t rows, uint64_t workspace_bytes)
 {
-    const dim3 grid((rows + 31u) / 32u, (m + (uint32_t)(MB * 32) - 1u) / (uint32_t)(MB * 32));
+    static const int lab_zs = lab_int("GGQ_MF32_ZS", 1, 64);                         // lab builds only, read once (-1 in the shipped library)
+    uint32_t zs = 1;
+    if (lab_zs >= 1) zs = (uint32_t)lab_zs;
+    else if (workgroups <= 128u && n_spans >= 16u) zs = workgroups <= 48u ? 4u : 2u;
+    // (profiles/r06_splitk_across_workgroups.json, slices 1 / 2 / 4 / 6 / 8 / 12 / 16: on 3072 x 12288 two slices take 30.2 -> 20.8 us at 32 rows of x and 38.0 -> 25.5 at 64, more slices only add
+    // partial-sum traffic; with two tiles of x -- 192 workgroups -- or 9216+ rows of W every split costs 5-60 %)
+    if (zs > n_spans) zs = n_spans;
+    if (zs < 2u || (uint64_t)zs * m * rows * 4u > workspace_bytes) return 1u;
+    return zs;
+}
+
+template <class F, int OUT, int MB>
+hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, void* workspace, uint64_t workspace_bytes,
+                       hipStream_t s)
+{
+    dim3 grid((rows + 31u) / 32u, (m + (uint32_t)(MB * 32) - 1u) / (uint32_t)(MB * 32));
     int dev = 0;
     (void)hipGetDevice(&dev);
     static const int lab_kw = lab_int("GGQ_MF32_KW", 1, 16);                         // lab builds only, read once (-1 in the shipped library)
     constexpr uint32_t cap = (uint32_t)mf_max_waves(MB);
     const uint32_t n_spans = (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN;
+    const uint32_t zs = workspace != nullptr ? mf_splitk(grid.x * grid.y, n_spans, m, rows, workspace_bytes) : 1u;
+    grid.z = zs;
     // Measured (profiles/r06_mfma32_ksplit_width_sweep.json, widths 4 / 6 / 8 / 12 at 32..256 rows of x): 4 waves stay best wherever the launch has a workgroup
     // per CU or more -- the kernel is bound by its x loads through L2, not by latency -- and 8 win 8-12 % when it has fewer than 256 workgroups (3072-row weights)
-    uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : (grid.x * grid.y < 256u ? 8u : 4u);
+    uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : (grid.x * grid.y * zs < 256u ? 8u : 4u);
+    const uint32_t per_z = (n_spans + zs - 1u) / zs;
     if (kw > cap) kw = cap;
-    if (kw > n_spans) kw = n_spans;
+    if (kw > per_z) kw = per_z;
     const uint32_t lds = mf_lds_bytes<F, MB>(kw);
     if (lds > 64 * 1024) {                      // beyond the default dynamic-LDS limit: raise it once per device for this instantiation
         static std::atomic<uint64_t> raised{0};
@@ -123,8 +143,14 @@ hipError_t launch_mfma(const void* packed, const void* x, const void* bias, void
         }
     }
     hipLaunchKernelGGL((linear_mfma<F, OUT, MB>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed), static_cast<const uint8_t*>(x),
-                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);
-    return hipGetLastError();
+                       static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols, zs > 1u ? static_cast<float*>(workspace) : nullptr);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess && zs > 1u) {
+        hipLaunchKernelGGL((splitk_reduce<OUT>), dim3((rows + 255u) / 256u, m), dim3(256), 0, s, static_cast<const float*>(workspace), static_cast<const uint8_t*>(bias),
+                           static_cast<uint8_t*>(y), m, rows, zs);
+        err = hipGetLastError();
+    }
+    return err;
 }
 
 // ---- the 16-row MFMA kernel (ggq_mfma16.hpp): tile = MB*16 rows of x  x  16 output columns, K split over KW waves of the workgroup.
@@ -144,7 +170,7 @@ uint32_t mf_waves(uint32_t tiles, uint32_t n_spans, uint32_t slots, uint32_t min
 }
 
 template <class F, int OUT, int MB>
-hipError_t launch_mfma16(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+hipError_t launch_mfma16(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, void*, uint64_t, hipStream_t s)
 {
     const dim3 grid((rows + 15u) / 16u, (m + (uint32_t)(MB * 16) - 1u) / (uint32_t)(MB * 16));
     int dev = 0;
@@ -183,7 +209,7 @@ hipError_t launch_tile_wm(const void* packed, const void* x, const void* bias, v
 }
 
 template <class F, int OUT>
-hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, hipStream_t s)
+hipError_t launch_tile(const void* packed, const void* x, const void* bias, void* y, uint32_t m, uint32_t rows, uint32_t cols, void*, uint64_t, hipStream_t s)
 {
 #ifdef GGQ_TILE_WM_AB      /* A/B builds (with -DGGQ_LAB) carry both shapes; the shipped library only the default one */
     static const int wm = lab_int("GGQ_TILE_WM", 2, 4);
@@ -211,8 +237,13 @@ uint32_t tile_min_m()
 
 }  // namespace
 
-extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
-                               void* y, int dtype, int tile_rows, void* hip_stream)
+namespace {
+
+// which of the MFMA_SHAPES a request runs as; -1 = GGQ_ERR_ARG
+int mfma_shape(const MfmaEntry* e, uint32_t rows, uint32_t cols, uint32_t m, int tile_rows, const void* y);
+
+int linear_mfma_impl(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                     void* y, int dtype, int tile_rows, void* workspace, uint64_t workspace_bytes, void* hip_stream)
 {
     const MfmaEntry* e = nullptr;
     for (const MfmaEntry& c : MFMA)
@@ -228,6 +259,18 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     // one decode per 32 / 64 / 128 rows of x); 256 = the shared-tile kernel (ggq_gemm.hpp: 256 x 256 output tile, weights decoded once per
     // workgroup into LDS; needs rows % 8 == 0); 0 = pick from m: one 32-row block up to m = 32, 64-row tiles to m < GGQ_TILE_MIN_M, the
     // shared-tile kernel from there on (profiles/r03_gemm_tile_bench.json).
+    const int shape = mfma_shape(e, rows, cols, m, tile_rows, y);
+    if (shape < 0) return GGQ_ERR_ARG;
+    if (shape == 3 && !aligned16(y)) return GGQ_ERR_ALIGN;                                // the shared-tile epilogue stores 16-byte vectors (ADVICE round 3)
+    if (workspace != nullptr && !aligned16(workspace)) return GGQ_ERR_ALIGN;
+    const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, workspace, workspace_bytes, static_cast<hipStream_t>(hip_stream));
+    return err == hipSuccess ? GGQ_OK : hip_fail(err);
+}
+
+int mfma_shape(const MfmaEntry* e, uint32_t rows, uint32_t cols, uint32_t m, int tile_rows, const void* y)
+{
+    (void)e;
+    const bool k_tail = cols % (uint32_t)MF_SPAN != 0;
     int shape;
     if (tile_rows == 0) {
         // the fastest FUSED shape for (m, rows).  The shared-tile kernel needs enough 256 x 256 tiles to fill the chip (one workgroup per CU, 256 CUs):
@@ -244,11 +287,37 @@ extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uin
     }
     else if (tile_rows == 16) shape = m <= 16 ? 4 : 5;              // the 16-row kernel (ggq_mfma16.hpp): one block of 16 rows of x per tile, else two (grid.y tiles beyond 32 rows)
     else if (tile_rows == 32 || tile_rows == 64 || tile_rows == 128 || tile_rows == 256) shape = tile_rows == 32 ? 0 : (tile_rows == 64 ? 1 : (tile_rows == 128 ? 2 : 3));
-    else return GGQ_ERR_ARG;
-    if (shape == 3 && (k_tail || rows % 8u != 0 || rows > (1u << 22))) return GGQ_ERR_ARG;   // whole spans only; 16-byte pieces of y; 32-bit offsets inside a tile's rows of y
-    if (shape == 3 && !aligned16(y)) return GGQ_ERR_ALIGN;                                // the shared-tile epilogue stores 16-byte vectors (ADVICE round 3)
-    const hipError_t err = e->fn[dtype][shape](packed, x, bias, y, m, rows, cols, static_cast<hipStream_t>(hip_stream));
-    return err == hipSuccess ? GGQ_OK : hip_fail(err);
+    else return -1;
+    if (shape == 3 && (k_tail || rows % 8u != 0 || rows > (1u << 22))) return -1;   // whole spans only; 16-byte pieces of y; 32-bit offsets inside a tile's rows of y
+    return shape;
+}
+
+}  // namespace
+
+extern "C" int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                               void* y, int dtype, int tile_rows, void* hip_stream)
+{
+    return linear_mfma_impl(qtype, packed, rows, cols, x, m, bias, y, dtype, tile_rows, nullptr, 0, hip_stream);
+}
+
+extern "C" int ggq_linear_mfma_ws(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                                  void* y, int dtype, int tile_rows, void* workspace, uint64_t workspace_bytes, void* hip_stream)
+{
+    return linear_mfma_impl(qtype, packed, rows, cols, x, m, bias, y, dtype, tile_rows, workspace, workspace_bytes, hip_stream);
+}
+
+extern "C" uint64_t ggq_linear_mfma_workspace(int qtype, uint32_t rows, uint32_t cols, uint32_t m, int tile_rows)
+{
+    const MfmaEntry* e = nullptr;
+    for (const MfmaEntry& c : MFMA)
+        if (c.qtype == qtype) e = &c;
+    if (!e || rows == 0 || cols == 0 || m == 0) return 0;
+    const int shape = mfma_shape(e, rows, cols, m, tile_rows, nullptr);
+    if (shape < 0 || shape > 2) return 0;                                                 // only the 32-row K-split kernel splits K across workgroups
+    const uint32_t mb = shape == 0 ? 1u : (shape == 1 ? 2u : 4u);
+    const uint32_t workgroups = ((rows + 31u) / 32u) * ((m + mb * 32u - 1u) / (mb * 32u)), n_spans = (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN;
+    const uint32_t zs = mf_splitk(workgroups, n_spans, m, rows, ~0ull);
+    return zs > 1u ? (uint64_t)zs * m * rows * 4u : 0u;
 }
 
 extern "C" int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,

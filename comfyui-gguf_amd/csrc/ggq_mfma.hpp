@@ -93,8 +93,10 @@ template <class F, int MB> constexpr uint32_t mf_lds_bytes(uint32_t kw)
 template <class F, int OUT, int MB>
 __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                              const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
-                                                             uint32_t m, uint32_t n_rows, uint32_t cols)
+                                                             uint32_t m, uint32_t n_rows, uint32_t cols, float* __restrict__ partial_)
 {
+    // partial_ != nullptr: K is ALSO split across workgroups (gridDim.z slices of whole spans, round 6): this workgroup contracts its slice only and stores its fp32
+    // partial sums to partial_[blockIdx.z][m][n_rows]; splitk_reduce adds the slices in order, the bias, and casts -- deterministic, like the in-workgroup sum.
     using G = MfmaGeom<F>;
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
     constexpr int CPB = F::BS / 8;                                                 // chunks per block
@@ -115,6 +117,10 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
     const uint32_t n_spans = (cols + MF_SPAN - 1) / MF_SPAN;
     const uint32_t tail_len = cols - (n_spans - 1) * (uint32_t)MF_SPAN;           // elements of the LAST span: 256, or a multiple of 64 below it (32-element blocks only)
     auto span_len = [&](uint32_t span) { return span + 1 == n_spans ? tail_len : (uint32_t)MF_SPAN; };
+    // this workgroup's slice of the spans: [lo, hi)
+    const uint32_t per_z = (n_spans + gridDim.z - 1) / gridDim.z;
+    const uint32_t lo = blockIdx.z * per_z, hi = (lo + per_z < n_spans) ? lo + per_z : n_spans;
+    const uint32_t first = lo + (uint32_t)wave;                                    // this wave's first span
     uint8_t* slice = smem + wave * PER_WAVE;
     uint8_t* xs = slice + G::SLICE;
 
@@ -159,16 +165,16 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
     };
 
     u32x4 pf[G::NUW];
-    if ((uint32_t)wave < n_spans) fetch((uint32_t)wave, pf);
+    if (first < hi) fetch(first, pf);
 
     if constexpr (!XLDS) {
         const uint32_t mr = m0 + (uint32_t)r;
         const GGQ_GLOBAL uint8_t* xrow = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
-        for (uint32_t span = (uint32_t)wave; span < n_spans; span += kw) {
+        for (uint32_t span = first; span < hi; span += kw) {
 #pragma unroll
             for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
             wave_sync();
-            if (span + kw < n_spans) fetch(span + kw, pf);                         // the next span's bytes fly while this one is decoded
+            if (span + kw < hi) fetch(span + kw, pf);                              // the next span's bytes fly while this one is decoded
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
             const uint32_t kbyte = span * (uint32_t)(MF_SPAN * 2);
@@ -202,23 +208,23 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
         const uint32_t swr = mf_swz((uint32_t)r);                                  // rows 32 mb + r swizzle like row r
         u32x4 ring[2][NX];                                                         // pieces g and g+1 in flight while piece g-1 is consumed
         auto xfetch = [&](uint32_t piece, u32x4 (&dst)[NX]) {                      // piece = index over the wave's own sequence of 32-element pieces
-            // the wave's p-th piece: span = wave + kw (p / 8), t = p % 8
-            const uint32_t kb = (((uint32_t)wave + kw * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
+            // the wave's p-th piece: span = first + kw (p / 8), t = p % 8
+            const uint32_t kb = ((first + kw * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
 #pragma unroll
             for (int i = 0; i < NX; i++) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
         };
-        const uint32_t my_spans = ((uint32_t)wave < n_spans) ? (n_spans - (uint32_t)wave + kw - 1) / kw : 0u;
+        const uint32_t my_spans = (first < hi) ? (hi - first + kw - 1) / kw : 0u;
         // 8 pieces of 32 elements per span; the wave that owns the LAST span has fewer in it when that span is short
-        const bool owns_last = my_spans > 0 && (uint32_t)wave + kw * (my_spans - 1) == n_spans - 1;
+        const bool owns_last = my_spans > 0 && first + kw * (my_spans - 1) == n_spans - 1;
         const uint32_t my_pieces = my_spans * 8u - (owns_last ? (uint32_t)(MF_SPAN - tail_len) / 32u : 0u);
         if (my_pieces > 0) xfetch(0u, ring[0]);
         if (my_pieces > 1) xfetch(1u, ring[1]);
         uint32_t piece = 0;
-        for (uint32_t span = (uint32_t)wave; span < n_spans; span += kw) {
+        for (uint32_t span = first; span < hi; span += kw) {
 #pragma unroll
             for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
             wave_sync();
-            if (span + kw < n_spans) fetch(span + kw, pf);
+            if (span + kw < hi) fetch(span + kw, pf);
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
             const uint8_t* wspan = slice + r * G::ROW_STRIDE + a;
             const uint32_t len = span_len(span);
@@ -263,8 +269,12 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
         for (uint32_t i = (uint32_t)wave; i < 16u; i += kw) {
             float v = red[i * 64 + lane];
             for (uint32_t w = 1; w < kw; w++) v += red[((w * 16u + i) * 64u) + lane];
-            v += bias;
             const uint32_t mr = m0 + (uint32_t)(mb * 32) + (i & 3u) + 8u * (i >> 2) + 4u * (uint32_t)h;
+            if (partial_ != nullptr) {
+                if (mr < m && ncol < n_rows) partial_[((size_t)blockIdx.z * m + mr) * n_rows + ncol] = v;
+                continue;
+            }
+            v += bias;
             if (mr < m && ncol < n_rows) {
                 uint16_t o;
                 if constexpr (OUT == OUT_F16) o = __builtin_bit_cast(uint16_t, (_Float16)v);
@@ -273,6 +283,26 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
             }
         }
     }
+}
+
+// y[mr][n] = cast(sum over the gridDim.z slices of partial[z][mr][n], in slice order, + bias[n]): the second pass of a launch whose K was split across workgroups
+template <int OUT>
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ partial, const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_, uint32_t m, uint32_t n_rows, uint32_t zs)
+{
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x, mr = blockIdx.y;         // (no integer division on the device: its expansion goes through fused multiply-adds)
+    if (n >= n_rows) return;
+    const uint64_t total = (uint64_t)m * n_rows, i = (uint64_t)mr * n_rows + n;
+    float v = partial[i];
+    for (uint32_t z = 1; z < zs; z++) v += partial[(uint64_t)z * total + i];
+    if (bias_ != nullptr) {
+        const uint16_t b = *reinterpret_cast<const uint16_t*>(bias_ + (size_t)n * 2);
+        if constexpr (OUT == OUT_F16) v += (float)__builtin_bit_cast(_Float16, b);
+        else v += bits_f32((uint32_t)b << 16);
+    }
+    uint16_t o;
+    if constexpr (OUT == OUT_F16) o = __builtin_bit_cast(uint16_t, (_Float16)v);
+    else o = (uint16_t)(pack_bf16(v, 0.0f) & 0xFFFFu);
+    *reinterpret_cast<uint16_t*>(y_ + i * 2) = o;
 }
 
 }  // namespace ggq

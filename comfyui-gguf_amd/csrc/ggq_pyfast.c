@@ -17,6 +17,8 @@ typedef int (*ggq_linear_mfma_fn)(int, const void*, uint32_t, uint32_t, const vo
 static ggq_dequant_fn g_dequant = NULL;
 static ggq_linear_small_fn g_small = NULL;
 static ggq_linear_mfma_fn g_mfma = NULL;
+typedef int (*ggq_linear_mfma_ws_fn)(int, const void*, uint32_t, uint32_t, const void*, uint32_t, const void*, void*, int, int, void*, uint64_t, void*);
+static ggq_linear_mfma_ws_fn g_mfma_ws = NULL;
 
 static PyObject* fast_bind(PyObject* self, PyObject* arg)
 {
@@ -31,15 +33,17 @@ static PyObject* fast_bind(PyObject* self, PyObject* arg)
 static PyObject* fast_bind_linear(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
 {
     (void)self;
-    if (nargs != 2) {
-        PyErr_SetString(PyExc_TypeError, "bind_linear(addr_small, addr_mfma)");
+    if (nargs != 3) {
+        PyErr_SetString(PyExc_TypeError, "bind_linear(addr_small, addr_mfma, addr_mfma_ws)");
         return NULL;
     }
     void* a = PyLong_AsVoidPtr(args[0]);
     void* b = PyLong_AsVoidPtr(args[1]);
+    void* c = PyLong_AsVoidPtr(args[2]);
     if (PyErr_Occurred()) return NULL;
     g_small = (ggq_linear_small_fn)a;
     g_mfma = (ggq_linear_mfma_fn)b;
+    g_mfma_ws = (ggq_linear_mfma_ws_fn)c;
     Py_RETURN_NONE;
 }
 
@@ -83,6 +87,21 @@ static PyObject* fast_linear_mfma(PyObject* self, PyObject* const* args, Py_ssiz
                                   (const void*)(uintptr_t)v[6], (void*)(uintptr_t)v[7], (int)v[8], (int)v[9], (void*)(uintptr_t)v[10]));
 }
 
+/* linear_mfma_ws(qtype, packed, rows, cols, x, m, bias | None, y, dtype, tile_rows, workspace | None, workspace_bytes, stream) -> ggq_status */
+static PyObject* fast_linear_mfma_ws(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
+{
+    (void)self;
+    unsigned long long v[13];
+    if (nargs != 13 || g_mfma_ws == NULL) {
+        PyErr_SetString(PyExc_TypeError, "linear_mfma_ws(qtype, packed, rows, cols, x, m, bias, y, dtype, tile_rows, workspace, workspace_bytes, stream) after bind_linear()");
+        return NULL;
+    }
+    if (as_u64s(args, 13, v)) return NULL;
+    return PyLong_FromLong(g_mfma_ws((int)v[0], (const void*)(uintptr_t)v[1], (uint32_t)v[2], (uint32_t)v[3], (const void*)(uintptr_t)v[4], (uint32_t)v[5],
+                                     (const void*)(uintptr_t)v[6], (void*)(uintptr_t)v[7], (int)v[8], (int)v[9], (void*)(uintptr_t)v[10], (uint64_t)v[11],
+                                     (void*)(uintptr_t)v[12]));
+}
+
 /* dequant(qtype, packed_ptr, n_blocks, out_ptr, compute_dtype, out_dtype, stream) -> ggq_status */
 static PyObject* fast_dequant(PyObject* self, PyObject* const* args, Py_ssize_t nargs)
 {
@@ -110,9 +129,10 @@ static PyObject* fast_dequant(PyObject* self, PyObject* const* args, Py_ssize_t 
 static PyMethodDef fast_methods[] = {
     {"bind", (PyCFunction)fast_bind, METH_O, "bind(address of ggq_dequant)"},
     {"dequant", (PyCFunction)(void (*)(void))fast_dequant, METH_FASTCALL, "ggq_dequant through a plain function pointer"},
-    {"bind_linear", (PyCFunction)(void (*)(void))fast_bind_linear, METH_FASTCALL, "bind_linear(address of ggq_linear_small, address of ggq_linear_mfma)"},
+    {"bind_linear", (PyCFunction)(void (*)(void))fast_bind_linear, METH_FASTCALL, "bind_linear(address of ggq_linear_small, address of ggq_linear_mfma, address of ggq_linear_mfma_ws)"},
     {"linear_small", (PyCFunction)(void (*)(void))fast_linear_small, METH_FASTCALL, "ggq_linear_small through a plain function pointer"},
     {"linear_mfma", (PyCFunction)(void (*)(void))fast_linear_mfma, METH_FASTCALL, "ggq_linear_mfma through a plain function pointer"},
+    {"linear_mfma_ws", (PyCFunction)(void (*)(void))fast_linear_mfma_ws, METH_FASTCALL, "ggq_linear_mfma_ws through a plain function pointer"},
     {NULL, NULL, 0, NULL},
 };
 
@@ -121,7 +141,7 @@ static struct PyModuleDef fast_module = {PyModuleDef_HEAD_INIT, "_ggq_fast", "fa
 /* ABI: the version of include/ggq.h whose three signatures this file was written against.  _native.fast() refuses a binary whose
  * constant differs from the loaded library's ggq_abi_version(): a stale _ggq_fast would call through raw pointers with the wrong
  * argument lists. */
-#define GGQ_FAST_ABI 10
+#define GGQ_FAST_ABI 11
 
 PyMODINIT_FUNC PyInit__ggq_fast(void)
 {

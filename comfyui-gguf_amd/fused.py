@@ -21,16 +21,19 @@ from .dequant import (GGQUnsupported, _DEVICE_OK, _HIP_TABLE, _OUT_CODE, _as_byt
 
 MAX_ROWS = 4
 _F16, _BF16 = torch.float16, torch.bfloat16
-_small_call = None        # ggq_linear_small / ggq_linear_mfma: the CPython binding (csrc/ggq_pyfast.c) when built, else ctypes -- same C entry points
+_small_call = None        # ggq_linear_small / ggq_linear_mfma(_ws): the CPython binding (csrc/ggq_pyfast.c) when built, else ctypes -- same C entry points
 _mfma_call = None
+_mfma_ws_call = None
+_ws_bytes = {}            # (qtype id, rows, cols, m, tile_rows) -> bytes of scratch ggq_linear_mfma_workspace() asks for (0 for most shapes): asked once per shape
 
 
 def _bind():
-    global _small_call, _mfma_call
+    global _small_call, _mfma_call, _mfma_ws_call
     fast = _native.fast()
     L = _native.lib()
     _small_call = fast.linear_small if fast is not None else L.ggq_linear_small
     _mfma_call = fast.linear_mfma if fast is not None else L.ggq_linear_mfma
+    _mfma_ws_call = fast.linear_mfma_ws if fast is not None else L.ggq_linear_mfma_ws
 
 
 def _prepare(x, weight, bias, dequant_dtype, what, dtypes, need_cols_256):
@@ -167,6 +170,15 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
                              f"32-element-block formats, {AUTO_MAX_ROWS_LEGACY_5BIT} for Q5_0 / Q5_1); pass tile_rows= to force a fused shape")
     if _mfma_call is None:
         _bind()
+    # K split across workgroups for weights with few, long rows (include/ggq.h ggq_linear_mfma_ws): the library says how much scratch it would use for this shape
+    # (0 for most: asked once per shape), torch's caching allocator provides it, stream-ordered like y
+    key = (qid, rows, cols, m, tile_rows)
+    ws = _ws_bytes.get(key)
+    if ws is None:
+        ws = _ws_bytes[key] = int(_native.lib().ggq_linear_mfma_workspace(qid, rows, cols, m, int(tile_rows)))
+    if ws:
+        scratch = torch.empty(ws, dtype=torch.uint8, device=x.device)
+        return _run(_mfma_ws_call, "ggq_linear_mfma_ws", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows), scratch.data_ptr(), ws), weight_to)
     return _run(_mfma_call, "ggq_linear_mfma", qid, weight, rows, cols, xf, m, bias, x, (int(tile_rows),), weight_to)
 
 
@@ -225,6 +237,14 @@ def _op_body(call_name, x, packed, bias, qtype, rows, cols, extra):
     y = torch.empty((m, rows), dtype=x.dtype, device=x.device)
     args = (qtype, packed.data_ptr(), rows, cols, xf.data_ptr(), m, None if bias is None else bias.data_ptr(), y.data_ptr(), _OUT_CODE[x.dtype]) + extra
     call = _small_call if call_name == "ggq_linear_small" else _mfma_call
+    if call_name == "ggq_linear_mfma":
+        key = (qtype, rows, cols, m, extra[0])
+        ws = _ws_bytes.get(key)
+        if ws is None:
+            ws = _ws_bytes[key] = int(_native.lib().ggq_linear_mfma_workspace(qtype, rows, cols, m, extra[0]))
+        if ws:
+            scratch = torch.empty(ws, dtype=torch.uint8, device=x.device)
+            call, args = _mfma_ws_call, args + (scratch.data_ptr(), ws)
     with torch.cuda.device(index):
         rc = call(*args, _raw_stream(index))
     if rc == _native.GGQ_ERR_ARG:

@@ -190,12 +190,23 @@ int ggq_linear_small(int qtype, const void* packed, uint32_t rows, uint32_t cols
  * from the packed blocks on v_mfma_f32_32x32x16_{f16,bf16}: each lane decodes the 8 consecutive weights that ARE its MFMA operand, the
  * dense weight never exists in memory.  x, bias, y of `dtype` in {GGQ_F16, GGQ_BF16}, contiguous, x 16-byte aligned; cols % 256 == 0 -- for the 32-element
  * block formats cols % 64 == 0 suffices (a shorter last span; not with tile_rows 256) -- GGQ_ERR_ARG otherwise: the caller keeps dequantize + GEMM.
- * tile_rows = rows of x per workgroup tile: 32 / 64 / 128 / 256, 0 = auto.
+ * tile_rows = rows of x per workgroup tile: 16 (the 16-row kernel on v_mfma_f32_16x16x32, csrc/ggq_mfma16.hpp: up to 32 rows of x per tile) / 32 / 64 / 128 / 256, 0 = auto
+ * (16-row kernel up to 8 rows of x -- 16 on weights of at most 4096 rows --, 32-row tiles to 32 rows, 64-row tiles above).
  * Weights bit-identical to the reference's, fp32 accumulation in the MFMA's order, K split over 4 waves and summed in a fixed order
  * (deterministic).  Replaces (install()'s default for up to 256 rows of x; `exact` turns it off): GGMLOps.Linear.forward_ggml_cast_weights
  * (ops.py:242-244) = get_weight + F.linear. */
 int ggq_linear_mfma(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
                     void* y, int dtype, int tile_rows, void* hip_stream);
+
+/* The same with a caller-provided scratch buffer (device memory, 16-byte aligned, `workspace_bytes` long; torch's allocator owns it, the call only
+ * uses it until the kernels it enqueued have run): a weight with few rows and long rows (FLUX `mlp.2` 3072 x 12288: 96 workgroups of the 32-row kernel on 256 CUs)
+ * then has its K ALSO split across workgroups -- every workgroup stores fp32 partial sums of its slice of whole spans, a second small kernel adds the slices in
+ * order (deterministic), the bias, and casts.  ggq_linear_mfma_workspace() = the bytes the library would use for that request (0: it would not split; a smaller or
+ * NULL workspace is never an error, the launch just keeps K inside the workgroups).  Same numerics statement as ggq_linear_mfma; same reference interface
+ * (ops.py:242-244). */
+int ggq_linear_mfma_ws(int qtype, const void* packed, uint32_t rows, uint32_t cols, const void* x, uint32_t m, const void* bias,
+                       void* y, int dtype, int tile_rows, void* workspace, uint64_t workspace_bytes, void* hip_stream);
+uint64_t ggq_linear_mfma_workspace(int qtype, uint32_t rows, uint32_t cols, uint32_t m, int tile_rows);
 
 #ifdef __cplusplus
 }

@@ -41,8 +41,9 @@ def test_fused_linears_are_no_further_from_fp64_than_unpack_plus_f_linear(pkg):
     for c in out["cases"]:
         if c.get("fused"):
             # the default's policy (fused.linear_auto): one row -> the GEMV unless the weight is 16384+ rows tall or its rows do not fit the GEMV's LDS staging
-            small = c["m"] == 1 and c["rows"] < 16384 and c["cols"] <= 6144
-            assert c["fused"] == ("ggq_linear_small" if small else "ggq_linear_mfma"), c
+            bs, ts = pkg.qtypes.block_geometry(pkg.qtypes.Q[c["qtype"]])
+            small = c["m"] == 1 and c["rows"] < 16384 and c["cols"] // bs * ts + 15 <= 6 * 64 * 16      # (csrc/ggq_linear.hpp LIN_SLICE)
+            assert c["fused"] == ("ggq_linear_small" if small else "ggq_linear_mfma"), (c["qtype"], c["rows"], c["cols"], c["m"], c["dtype"], c["fused"])
 
 
 def test_the_committed_table_says_what_the_default_claims():

@@ -103,6 +103,54 @@ def test_mfma16_linear_against_fp64_reference(pkg, name, kind):
         assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=16, auto_max_rows=None))
 
 
+@pytest.mark.parametrize("name", ["Q4_K", "Q5_K", "Q8_0", "Q6_K"])
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_k_split_across_workgroups_with_a_workspace(pkg, name, kind):
+    """Round 6: a weight with few, long rows gets its K split across workgroups as well (ggq_linear_mfma_ws + splitk_reduce) when the caller provides scratch -- fused.linear_mfma
+    asks ggq_linear_mfma_workspace() once per shape and allocates it.  Shapes with 16+ spans and < 256 workgroups: ragged rows of x and of W, one and several tiles of x, a slice count that
+    does not divide the spans; tolerance against fp64 on the oracle's weights, deterministic, an exact-arithmetic case (a slice dropped or added twice cannot hide), and the C entry point
+    directly: a NULL or too-small workspace is not an error, it keeps K inside the workgroups (bit-equal to ggq_linear_mfma)."""
+    q = pkg.qtypes.Q[name]
+    dtype, eps = DT[kind]
+    L, nat = pkg._native.lib(), pkg._native
+    g = torch.Generator(device=DEV)
+    g.manual_seed(29)
+    for rows, cols, m, with_bias, tile in ((96, 8192, 33, True, 0), (40, 12288, 64, False, 0), (200, 4352, 100, True, 64), (64, 5120, 130, True, 128)):
+        ws = int(L.ggq_linear_mfma_workspace(int(q), rows, cols, m, tile))
+        assert ws > 0 and ws % (m * rows * 4) == 0, (rows, cols, m, ws)                     # zs slices of m x rows fp32 partials
+        blocks = pkg.synth.make_tensor_bytes(q, (rows, cols), seed=rows + cols, mode="signed")
+        w = pkg.ops.GGMLTensor(torch.from_numpy(blocks).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+        x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(dtype)
+        bias = (torch.randn(rows, device=DEV, generator=g) * 0.01).to(dtype) if with_bias else None
+        y = pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None)
+        _check(y, x, _dense_weight(q, blocks, kind, rows, cols), bias, eps, cols)
+        assert torch.equal(y, pkg.fused.linear_mfma(x, w, bias, tile_rows=tile, auto_max_rows=None))
+        # the C ABI directly: no workspace / one that is too small -> the launch keeps K inside the workgroups and returns what ggq_linear_mfma returns
+        code = nat.BF16 if kind == "bf16" else nat.F16
+        stream = torch.cuda.current_stream().cuda_stream
+        args = (int(q), w.data_ptr(), rows, cols, x.data_ptr(), m, None if bias is None else bias.data_ptr())
+        y0, y1, y2, y3 = (torch.empty(m, rows, dtype=dtype, device=DEV) for _ in range(4))
+        small = torch.empty(64, dtype=torch.uint8, device=DEV)
+        full = torch.empty(ws, dtype=torch.uint8, device=DEV)
+        assert L.ggq_linear_mfma(*args, y0.data_ptr(), code, tile, stream) == nat.GGQ_OK
+        assert L.ggq_linear_mfma_ws(*args, y1.data_ptr(), code, tile, None, 0, stream) == nat.GGQ_OK
+        assert L.ggq_linear_mfma_ws(*args, y2.data_ptr(), code, tile, small.data_ptr(), 64, stream) == nat.GGQ_OK
+        assert L.ggq_linear_mfma_ws(*args, y3.data_ptr(), code, tile, full.data_ptr(), ws, stream) == nat.GGQ_OK
+        assert L.ggq_linear_mfma_ws(*args, y3.data_ptr(), code, tile, full.data_ptr() + 4, ws - 4, stream) == nat.GGQ_ERR_ALIGN
+        assert torch.equal(y0, y1) and torch.equal(y0, y2) and torch.equal(y3, y)
+    assert L.ggq_linear_mfma_workspace(int(q), 12288, 3072, 64, 0) == 0                      # enough workgroups: no split
+    assert L.ggq_linear_mfma_workspace(int(q), 96, 8192, 4, 0) == 0                          # 4 rows of x: the 16-row kernel, which fills the chip by itself
+    # exact arithmetic through the split
+    rows, cols, m = 70, 8192, 37
+    eb = _exact_blocks(pkg, q, rows, cols, seed=6)
+    ew = pkg.ops.GGMLTensor(torch.from_numpy(eb).to(DEV), tensor_type=q, tensor_shape=(rows, cols))
+    w64 = _dense_weight(q, eb, kind, rows, cols)
+    xi = torch.randint(-2, 3, (m, cols), device=DEV, generator=g).to(dtype)
+    x64 = xi.double().cpu().numpy()
+    assert (np.abs(x64) @ np.abs(w64).T).max() < 2.0 ** 16 and L.ggq_linear_mfma_workspace(int(q), rows, cols, m, 0) > 0
+    assert torch.equal(pkg.fused.linear_mfma(xi, ew).cpu(), torch.from_numpy(x64 @ w64.T).to(dtype)), (name, kind, "exact through split-K")
+
+
 def _exact_blocks(pkg, q, rows, cols, seed):
     """Packed blocks whose scale fields are powers of two: every weight, every product with a small integer and every partial
     sum is exactly representable in fp32."""
@@ -126,7 +174,8 @@ def test_exact_arithmetic_cases_are_bit_equal(pkg, name, kind):
     assert np.all(w64 * 2.0 ** 8 == np.round(w64 * 2.0 ** 8)) and np.abs(w64).max() < 64       # every weight a multiple of 2^-8
     g = torch.Generator(device=DEV).manual_seed(3)
     mfma16 = lambda t: (lambda x, w: pkg.fused.linear_mfma(x, w, tile_rows=t))
-    for m, fn in ((37, pkg.fused.linear_mfma), (3, pkg.fused.linear_small), (160, pkg.fused.linear_mfma), (1, mfma16(16)), (13, mfma16(16)), (29, mfma16(16)),
+    forced = lambda x, w: pkg.fused.linear_mfma(x, w, auto_max_rows=None)        # (the auto policy declines 32-element-block formats above 128 rows of x)
+    for m, fn in ((37, pkg.fused.linear_mfma), (3, pkg.fused.linear_small), (160, forced), (1, mfma16(16)), (13, mfma16(16)), (29, mfma16(16)),
                   (5, mfma16(0)), (12, mfma16(0))):
         x = torch.randint(-4, 5, (m, cols), device=DEV, generator=g).to(dtype)
         x64 = x.double().cpu().numpy()

@@ -458,14 +458,15 @@ def test_autograd_through_the_default_install(mods, pkg, dev):
         calls = []
         if pkg.fused._small_call is None:
             pkg.fused._bind()
-        real_small, real_mfma = pkg.fused._small_call, pkg.fused._mfma_call
+        real_small, real_mfma, real_ws = pkg.fused._small_call, pkg.fused._mfma_call, pkg.fused._mfma_ws_call
         pkg.fused._small_call = lambda *a: (calls.append("small"), real_small(*a))[1]
         pkg.fused._mfma_call = lambda *a: (calls.append("mfma"), real_mfma(*a))[1]
+        pkg.fused._mfma_ws_call = lambda *a: (calls.append("mfma"), real_ws(*a))[1]
         try:
             for m in (1, 2, 40):
                 lin(torch.randn(m, 512, device=dev, dtype=torch.float16))
         finally:
-            pkg.fused._small_call, pkg.fused._mfma_call = real_small, real_mfma
+            pkg.fused._small_call, pkg.fused._mfma_call, pkg.fused._mfma_ws_call = real_small, real_mfma, real_ws
         assert calls == ["small", "mfma", "mfma"], f"under no_grad the default install runs the fused kernels (one row: the GEMV; more: the MFMA kernels), got {calls}"
 
 

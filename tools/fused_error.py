@@ -60,13 +60,14 @@ def measure(pkg, device, ms=(1, 4, 64, 256), dtypes=("bf16", "f16"), models=("fl
     # which C entry point the policy really called: the two bindings are wrapped for the duration of the measurement
     if fused._small_call is None:
         fused._bind()
-    real_small, real_mfma, ran = fused._small_call, fused._mfma_call, []
+    real_small, real_mfma, real_ws, ran = fused._small_call, fused._mfma_call, fused._mfma_ws_call, []
     fused._small_call = lambda *a: (ran.append("ggq_linear_small"), real_small(*a))[1]
     fused._mfma_call = lambda *a: (ran.append("ggq_linear_mfma"), real_mfma(*a))[1]
+    fused._mfma_ws_call = lambda *a: (ran.append("ggq_linear_mfma"), real_ws(*a))[1]          # (the same kernels with K also split across workgroups)
     try:
         return _measure(pkg, device, ms, dtypes, models, shapes, seed, with_bias, ran, T, F, fused, dq, oracle, gen, cases)
     finally:
-        fused._small_call, fused._mfma_call = real_small, real_mfma
+        fused._small_call, fused._mfma_call, fused._mfma_ws_call = real_small, real_mfma, real_ws
 
 
 def _measure(pkg, device, ms, dtypes, models, shapes, seed, with_bias, ran, T, F, fused, dq, oracle, gen, cases):
