@@ -105,7 +105,17 @@ template <class F> struct TileSpan {
     static constexpr int SPAN_BYTES = SPAN / F::BS * F::TS;
     // a span may start at any 2-byte boundary (Q6_K 210 B, Q3_K 110 B, 4 x 34 B, ...): every row keeps its own leading misalignment
     static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0;
-    static constexpr int U = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;         // 16-byte load units per row
+    // 16-byte load units per row, made ODD: the staging is filled linearly by LDS-DMA (unit u at u * 16), so its row pitch IS U units, and the decode reads 16 rows per
+    // wave -- at an even pitch rows 8 apart (Q3_K's 8 units: EVERY row) fall on the same banks.  The extra unit of a row is never loaded (masked like the units past
+    // the span) and never read.
+    // Measured against the even-pitch build (profiles/r06_lds_row_pitch.json): Q3_K (8 -> 9 units) 34-40 % faster, Q6_K (14 -> 15) up to 8 %, Q8_0 / IQ4_XS (10 -> 11)
+    // 0-1 %; the 6-unit rows (Q4_0, IQ4_NL, Q5_1: rows 8 apart share banks, a 2-way conflict) ran 1-3 % SLOWER at 7 and stay at 6.
+    static constexpr int U0 = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;
+#ifdef GGQ_GT_EVEN_PITCH   /* A/B builds only: rounds 2-5 */
+    static constexpr int U = U0;
+#else
+    static constexpr int U = U0 == 6 ? U0 : (U0 | 1);
+#endif
     static constexpr int ROW_STRIDE = U * 16;
 };
 

@@ -177,8 +177,13 @@ hipError_t launch_mfma16(const void* packed, const void* x, const void* bias, vo
     (void)hipGetDevice(&dev);
     static const int lab_kw = lab_int("GGQ_MF16_KW", 1, MF16_MAX_WAVES);             // lab builds only, read once (-1 in the shipped library)
     const uint32_t n_spans = (cols + (uint32_t)MF_SPAN - 1u) / (uint32_t)MF_SPAN;
-    const uint32_t slots = compute_units(dev) * 4u * (MB == 1 ? 6u : 4u);            // waves the chip holds at this instantiation's register count
-    const uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : mf_waves(grid.x * grid.y, n_spans, slots, 2u, (uint32_t)MF16_MAX_WAVES);
+    // waves the chip holds at this instantiation's register count (per SIMD: 6 / 4 measured best for the formats that fit 96 / 128 registers; the ones that asked
+    // for more registers hold 4 / 3 -- with 6 assumed they were launched 4.5 waves per SIMD wide and ran a second round: 12-15 % slower, profiles/r06_mfma16_spills.json)
+    constexpr uint32_t per_simd = MB == 1 ? (Mf16Occ<F>::MB1 >= 5 ? 6u : 4u) : (Mf16Occ<F>::MB2 >= 4 ? 4u : 3u);
+    const uint32_t slots = compute_units(dev) * 4u * per_simd;
+    constexpr uint32_t cap = (uint32_t)mf16_max_waves<F, MB>();
+    uint32_t kw = lab_kw >= 1 ? (uint32_t)lab_kw : mf_waves(grid.x * grid.y, n_spans, slots, 2u, cap);
+    if (kw > cap) kw = cap;
     const uint32_t lds = mf16_lds_bytes<F, MB>(kw);
     hipLaunchKernelGGL((linear_mfma16<F, OUT, MB>), grid, dim3(kw * 64u), lds, s, static_cast<const uint8_t*>(packed),
                        static_cast<const uint8_t*>(x), static_cast<const uint8_t*>(bias), static_cast<uint8_t*>(y), m, rows, cols);

@@ -58,11 +58,19 @@ template <class F> struct MfmaGeom {
     // unaligned too: with a short last span (cols % 256 != 0: SD3.5's 2432 columns) a ROW is no longer a multiple of 16 bytes (Q5_0: 1672), so the rows of a
     // tile start at different offsets mod 16 although every span is 176 bytes (treating them as aligned made the 16-byte loads of odd rows
     // start unaligned and the last one reach up to 12 bytes past the row -- past the tensor on its last row)
+#ifdef GGQ_MF_LEGACY_ALIGNED   /* A/B builds only: rounds 2-5 (32-element formats treated as 16-byte aligned rows: wrong for cols % 256 != 0) */
+    static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0;
+#else
     static constexpr bool ALIGNED = SPAN_BYTES % 16 == 0 && F::BS != 32;
+#endif
     static constexpr int U = (SPAN_BYTES + (ALIGNED ? 0 : 14) + 15) / 16;         // 16-byte load units per row
-    static constexpr int ROW_STRIDE = U * 16;
+    // LDS pitch of a row: an ODD number of 16-byte units.  Lane r decodes row r, so a pitch of 12 units (Q5_0 once its rows count as unaligned: 192 B = 48 banks)
+    // puts rows r and r + 4 on the same banks -- measured 35-55 % slower than 11 units on SD3.5's Q5_0 layers (profiles/r06_lds_row_pitch.json); Q3_K's 8 units
+    // (128 B) was a 16-way conflict since round 2.  With an odd pitch only rows 16 apart share banks, whatever the format.
+    static constexpr int PITCH_U = U | 1;
+    static constexpr int ROW_STRIDE = PITCH_U * 16;
     static constexpr int NUW = (32 * U + 63) / 64;                                 // load units per lane
-    static constexpr int SLICE = NUW * 64 * 16;                                    // LDS bytes per wave
+    static constexpr int SLICE = ((NUW * 64 + U - 1) / U) * ROW_STRIDE;            // LDS bytes per wave: every unit a lane holds has a place, the ones past row 31 too
 };
 
 // MB = 32-row blocks of x per workgroup tile (1, 2, 4, 8).
@@ -166,13 +174,20 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
 
     u32x4 pf[G::NUW];
     if (first < hi) fetch(first, pf);
+    uint32_t stash_at[G::NUW];                                                     // where this lane's units go in the slice: row * pitch + piece * 16
+#pragma unroll
+    for (int u = 0; u < G::NUW; u++) {
+        const uint32_t unit = (uint32_t)(lane + 64 * u);
+        if constexpr (G::PITCH_U == G::U) stash_at[u] = unit * 16u;               // (one register + immediates)
+        else stash_at[u] = unit / (uint32_t)G::U * (uint32_t)G::ROW_STRIDE + unit % (uint32_t)G::U * 16u;
+    }
 
     if constexpr (!XLDS) {
         const uint32_t mr = m0 + (uint32_t)r;
         const GGQ_GLOBAL uint8_t* xrow = (GGQ_GLOBAL const uint8_t*)x_ + (uint64_t)(mr < m ? mr : m - 1) * cols * 2 + (uint32_t)(h * 64);
         for (uint32_t span = first; span < hi; span += kw) {
 #pragma unroll
-            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + stash_at[u]) = pf[u];
             wave_sync();
             if (span + kw < hi) fetch(span + kw, pf);                              // the next span's bytes fly while this one is decoded
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
         uint32_t piece = 0;
         for (uint32_t span = first; span < hi; span += kw) {
 #pragma unroll
-            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + (lane + 64 * u) * 16) = pf[u];
+            for (int u = 0; u < G::NUW; u++) *reinterpret_cast<u32x4*>(slice + stash_at[u]) = pf[u];
             wave_sync();
             if (span + kw < hi) fetch(span + kw, pf);
             const uint32_t a = G::ALIGNED ? 0u : ((uint32_t)(wrow_off + (uint64_t)span * G::SPAN_BYTES) & 15u);

@@ -77,11 +77,26 @@ template <class F, int MB> constexpr uint32_t mf16_lds_bytes(uint32_t kw)
 #ifndef GGQ_MF16_ABLATE
 #define GGQ_MF16_ABLATE 0       /* A/B builds only (WRONG results): 1 = no decode (the MFMA eats raw LDS bytes), 2 = no x loads, 3 = both: the floor of the load -> LDS -> MFMA -> reduce skeleton */
 #endif
-// occupancy the register allocator is asked for: 5 waves per SIMD with one block of x (80-96 registers, no spill for the K-quants), 4 with two
-#define GGQ_MF16_OCC(MB) __attribute__((amdgpu_waves_per_eu((MB) == 1 ? 5 : 4, 8)))
+// occupancy the register allocator is asked for: 5 waves per SIMD with one block of x (<= 96 registers), 4 with two (<= 128) -- where that fits.  The formats
+// whose rows start at any 2-byte offset carry more state (4-5 load units per lane, the skew, the tail masks) and SPILLED under those caps (Q8_0: 72-108 bytes of
+// scratch per lane, Q5_0 28-52, Q4_0 / IQ4_NL 12-44, IQ4_XS 8-36; Q6_K and Q5_1 with two blocks of x only): a spill is a vector-memory access in front of the
+// in-order weight stream, and Q8_0 ran at 25 us where the one-row GEMV takes 12 (profiles/r06_format_sweep.json).  They get one wave per SIMD less.
+template <class F> struct Mf16Occ { static constexpr int MB1 = 5, MB2 = 4; };
+#ifndef GGQ_MF16_UNIFORM_OCC   /* A/B builds only: the same caps for every format (round 6 before the format sweep) */
+template <> struct Mf16Occ<FmtQ4_0> { static constexpr int MB1 = 4, MB2 = 3; };
+template <> struct Mf16Occ<FmtQ5_0> { static constexpr int MB1 = 4, MB2 = 3; };
+template <> struct Mf16Occ<FmtQ8_0> { static constexpr int MB1 = 4, MB2 = 3; };
+template <> struct Mf16Occ<FmtIQ4_NL> { static constexpr int MB1 = 4, MB2 = 3; };
+template <> struct Mf16Occ<FmtIQ4_XS> { static constexpr int MB1 = 4, MB2 = 3; };
+template <> struct Mf16Occ<FmtQ6_K> { static constexpr int MB1 = 5, MB2 = 3; };
+template <> struct Mf16Occ<FmtQ5_1> { static constexpr int MB1 = 5, MB2 = 3; };
+#endif
+// the widest workgroup of an instantiation: 16 waves cap the allocator at 128 registers (4 waves per SIMD); the ones asked for 3 per SIMD get 12 (170 registers)
+template <class F, int MB> constexpr int mf16_max_waves() { return (MB == 2 && Mf16Occ<F>::MB2 < 4) ? 12 : MF16_MAX_WAVES; }
+#define GGQ_MF16_OCC(F, MB) __attribute__((amdgpu_waves_per_eu((MB) == 1 ? Mf16Occ<F>::MB1 : Mf16Occ<F>::MB2, 8)))
 
 template <class F, int OUT, int MB>
-__global__ __launch_bounds__(MF16_MAX_WAVES * 64) GGQ_MF16_OCC(MB) void linear_mfma16(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
+__global__ __launch_bounds__((mf16_max_waves<F, MB>()) * 64) GGQ_MF16_OCC(F, MB) void linear_mfma16(const uint8_t* __restrict__ packed_, const uint8_t* __restrict__ x_,
                                                                       const uint8_t* __restrict__ bias_, uint8_t* __restrict__ y_,
                                                                       uint32_t m, uint32_t n_rows, uint32_t cols)
 {

@@ -130,23 +130,21 @@ AUTO_MAX_ROWS = 256      # rows of x up to which a fused MFMA shape beats dequan
                          # and profiles/r04_gemm_skeleton_sweep.json shows why that gap does not close: DESIGN.md section 4c)
 
 
-# ... and, above 128 rows of x, the product (rows of x) x (rows of the weight) beyond which the K-split kernel's repeated decode (once per 64 rows of x) costs more than
-# one unpack + hipBLASLt: FLUX's 21504 x 3072 `linear1` at 192 / 256 rows runs 79.6 / 78.3 us fused against 63.2 / 68.6 us unpack + F.linear, while 12288 x 3072 at 256 rows
-# (52.9 vs 54.6) and everything smaller still wins or is level (profiles/r05_mfma_tile_choice_96_to_256_rows.json).  21504 x 192 = 4.1 M declines, 12288 x 256 = 3.1 M stays.
-AUTO_MAX_ROWS_TIMES_OUT = 3_600_000
-# ... and the 32-element-block formats (Q4_0 ... Q8_0, IQ4_NL) altogether above this many rows of x: at 256 rows SD3.5-large's Q5_0 layers (2432 columns) run 1.7-2.3x SLOWER fused than
-# unpack + hipBLASLt (66.9 vs 39.7 us at 7296 x 2432, 124.8 vs 53.2 at 14592 x 2432; profiles/r06_mid_m_sweep.json, threshold sweep profiles/r06_legacy_formats_row_threshold.json)
-AUTO_MAX_ROWS_LEGACY_BLOCKS = 128
-# ... and the two 5-bit ones among them (Q5_0, Q5_1: a fifth-bit plane to merge per chunk) already above 64: SD3.5's 7296 x 2432 Q5_0 at 32 / 64 / 96 / 128 rows runs 17.8 / 21.7 / 35.3 / 36.1 us
-# fused against 33.4 / 30.7 / 31.8 / 32.9 unpack + hipBLASLt (the same file); Q8_0 still wins at 128 rows on 4096- and 3072-row weights (21.6 vs 36.9, 46.6 vs 70.7)
-AUTO_MAX_ROWS_LEGACY_5BIT = 64
-_LEGACY_5BIT = (6, 7)          # ggml type ids of Q5_0, Q5_1
+# ... and, above 128 rows of x, the multiply-accumulates (rows of x) x (rows of W) x (columns) beyond which the K-split kernel's repeated decode (once per 64 rows of x) costs more
+# than one unpack + hipBLASLt.  Measured per format on FLUX / SD3.5 / T5 shapes at 64 ... 256 rows, two alternations (profiles/r06_fused_vs_unpack_row_threshold.json, us fused vs
+# unpack + F.linear): Q4_K 12288 x 3072 at 192 rows 46-48 vs 51-52 (7.2 G: stays), at 256 rows 60-61 vs 54-55 (9.7 G: declines), 4096 x 4096 at 256 rows 27 vs 32; the formats with
+# the dearer decode or the wider blocks cross earlier -- 12288 x 3072 at 192 rows: Q8_0 58 vs 50, Q6_K 61 vs 49, Q3_K 52 vs 49; Q5_0 9728 x 2432 at 256 rows (6.1 G) 49-51 vs 43,
+# at 192 rows (4.5 G) level; 4096 x 4096 at 256 rows (4.3 G) still ahead or level for all four.  Up to 128 rows every format is ahead or level on every shape measured.
+# (Rounds 5-6 used rows of x x rows of W > 3.6 M plus flat row limits of 128 / 64 for the 32-element-block formats: those limits had been measured on a 32-row kernel whose LDS
+# row pitch put every fourth row of a Q5_0 tile on the same banks -- EXPERIMENTS.md R6-10.)
+AUTO_MAX_MACS = 8.0e9
+AUTO_MAX_MACS_DEAR_DECODE = 5.0e9
+_DEAR_DECODE = (6, 8, 11, 14)          # ggml type ids of Q5_0, Q8_0, Q3_K, Q6_K
 
 
-def _legacy_row_limit(qid, block_size):
-    if block_size != 32:
-        return AUTO_MAX_ROWS
-    return AUTO_MAX_ROWS_LEGACY_5BIT if qid in _LEGACY_5BIT else AUTO_MAX_ROWS_LEGACY_BLOCKS
+def _auto_declines(qid, rows, cols, m, max_rows=AUTO_MAX_ROWS):
+    """True where `tile_rows=0` (auto) hands the call back to dequantize + F.linear."""
+    return m > max_rows or (m > 128 and m * rows * cols > (AUTO_MAX_MACS_DEAR_DECODE if qid in _DEAR_DECODE else AUTO_MAX_MACS))
 
 
 def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to=None, auto_max_rows=AUTO_MAX_ROWS):
@@ -156,18 +154,17 @@ def linear_mfma(x, weight, bias=None, dequant_dtype=None, tile_rows=0, weight_to
     tests/test_gpu_mfma.py).  Raises GGQUnsupported for anything the kernel does not take.
 
     ``tile_rows=0`` (auto) never picks something slower than the default path: the library chooses the fastest fused shape for
-    (rows of x, rows of the weight), and inputs of more than ``auto_max_rows`` rows -- or of more than 128 rows on a weight so tall that
-    rows of x times rows of the weight exceeds ``AUTO_MAX_ROWS_TIMES_OUT`` -- are DECLINED (GGQUnsupported: the caller keeps
-    dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
+    (rows of x, rows of the weight), and inputs of more than ``auto_max_rows`` rows -- or of more than 128 rows on a weight so large that
+    rows of x times its elements exceeds ``AUTO_MAX_MACS`` (``AUTO_MAX_MACS_DEAR_DECODE`` for Q5_0 / Q8_0 / Q3_K / Q6_K) -- are DECLINED
+    (GGQUnsupported: the caller keeps dequantize + F.linear, which is faster there).  An explicit ``tile_rows`` (32 / 64 / 128 = K-split kernel, 256 = shared-tile
     kernel) or ``auto_max_rows=None`` forces the fused kernel at any size."""
     qid, rows, cols, m, xf, bias = _prepare(x, weight, bias, dequant_dtype, "fused GEMM", (_F16, _BF16), True)
     if tile_rows not in (0, 16, 32, 64, 128, 256) or (tile_rows == 256 and (rows % 8 or cols % 256)):
         raise GGQUnsupported("fused GEMM: tile_rows is 0 (auto), 16, 32, 64, 128 or 256 (the shared-tile kernel: rows % 8 == 0, cols % 256 == 0)")
-    if tile_rows == 0 and auto_max_rows is not None and (m > auto_max_rows or (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)
-                                                          or m > _legacy_row_limit(qid, _HIP_TABLE[_qtype_key(qid)][1])):
-        raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x on {rows} output columns -- dequantize + F.linear is the faster path there "
-                             f"(above {auto_max_rows} rows; above 128 rows with rows x columns > {AUTO_MAX_ROWS_TIMES_OUT}; above {AUTO_MAX_ROWS_LEGACY_BLOCKS} rows for the "
-                             f"32-element-block formats, {AUTO_MAX_ROWS_LEGACY_5BIT} for Q5_0 / Q5_1); pass tile_rows= to force a fused shape")
+    if tile_rows == 0 and auto_max_rows is not None and _auto_declines(qid, rows, cols, m, auto_max_rows):
+        raise GGQUnsupported(f"fused GEMM (auto): {m} rows of x on a {rows} x {cols} weight -- dequantize + F.linear is the faster path there (above {auto_max_rows} rows; above 128 "
+                             f"rows when rows of x * rows * columns exceeds {AUTO_MAX_MACS:.1e}, {AUTO_MAX_MACS_DEAR_DECODE:.1e} for Q5_0 / Q8_0 / Q3_K / Q6_K); pass tile_rows= to "
+                             f"force a fused shape")
     if _mfma_call is None:
         _bind()
     # K split across workgroups for weights with few, long rows (include/ggq.h ggq_linear_mfma_ws): the library says how much scratch it would use for this shape
@@ -315,8 +312,7 @@ def linear_traced(layer, x, small_m, mfma_max_m):
     mfma = False
     if not small:
         k_ok = cols % 256 == 0 or (block_size == 32 and cols % 64 == 0)
-        mfma = (x.dtype in (_F16, _BF16) and k_ok and m <= mfma_max_m and m <= AUTO_MAX_ROWS and not (m > 128 and m * rows > AUTO_MAX_ROWS_TIMES_OUT)
-                and m <= _legacy_row_limit(qid, block_size))
+        mfma = x.dtype in (_F16, _BF16) and k_ok and m <= mfma_max_m and not _auto_declines(qid, rows, cols, m)
         if not mfma:
             return None
     if weight.device != x.device:

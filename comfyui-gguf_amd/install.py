@@ -24,7 +24,7 @@ reference's method.  The result matches F.linear up to fp32 summation order, not
 
 ``fused_mfma`` (or ``GGQ_FUSED_MFMA=1``; needs ``ref_ops``) wraps the same method for inputs of up to ``fused_mfma_max_m`` rows
 (default 256, ``GGQ_FUSED_MFMA_MAX_M``): fused dequantize + GEMM on the matrix cores (fused.linear_mfma), 1.2-3x faster than
-dequantize + hipBLASLt in that range on FLUX / T5 layer shapes; above it -- and above 128 rows on the tallest weights (fused.AUTO_MAX_ROWS_TIMES_OUT) -- hipBLASLt on
+dequantize + hipBLASLt in that range on FLUX / T5 layer shapes; above it -- and above 128 rows on the largest weights (fused.AUTO_MAX_MACS) -- hipBLASLt on
 the dense weight wins and keeps the job.  Same numerics statement; part of the default, off under ``exact``.
 
 ``gather_embedding`` (or ``GGQ_GATHER_EMBEDDING=1``; needs ``ref_ops``) wraps ``GGMLOps.Embedding.forward_ggml_cast_weights``

@@ -57,9 +57,16 @@ def test_auto_dispatch_reaches_the_shared_tile_kernel(pkg, name):
     x = (torch.randn(m, cols, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
     with pytest.raises(pkg.dequant.GGQUnsupported):
         pkg.fused.linear_mfma(x, w)                                                         # 2304 rows of x: declined by default
+    # above 128 rows of x the policy counts multiply-accumulates (fused.AUTO_MAX_MACS = 8e9, 5e9 for the formats with the dearer decode): a 16384 x 2048 weight is served at
+    # 200 rows of x (6.7e9) and declined at 256 (8.6e9) in Q4_K, served at 140 (4.7e9) and declined at 200 in Q8_0 / Q6_K
+    bs, ts = pkg.qtypes.block_geometry(q)
+    big = pkg.ops.GGMLTensor(torch.zeros(16384 * 2048 // bs * ts, dtype=torch.uint8, device=DEV), tensor_type=q, tensor_shape=(16384, 2048))
+    xb = torch.zeros(256, 2048, dtype=torch.bfloat16, device=DEV)
+    served, declined = (200, 256) if name == "Q4_K" else (140, 200)
+    assert pkg.fused.linear_mfma(xb[:served], big).shape == (served, 16384)
     with pytest.raises(pkg.dequant.GGQUnsupported):
-        pkg.fused.linear_mfma(x[:192], pkg.ops.GGMLTensor(torch.zeros(21504 * 256 // 256 * 144, dtype=torch.uint8, device=DEV), tensor_type=q, tensor_shape=(21504, 256))
-                              if name == "Q4_K" else w.as_subclass(torch.Tensor))          # 192 rows x 21504 output columns: the tall-weight rule (Q4_K leg)
+        pkg.fused.linear_mfma(xb[:declined], big)
+    del big, xb
     auto = pkg.fused.linear_mfma(x, w, auto_max_rows=None)
     tile, ksplit = pkg.fused.linear_mfma(x, w, tile_rows=256), pkg.fused.linear_mfma(x, w, tile_rows=128)
     _check(auto, x, _dense_weight(q, blocks, "bf16", rows, cols), None, DT["bf16"][1], cols)
@@ -67,12 +74,7 @@ def test_auto_dispatch_reaches_the_shared_tile_kernel(pkg, name):
     assert not torch.equal(ksplit, tile)                                                    # (the K-split kernel sums in another order: the two are distinguishable)
     small = pkg.fused.linear_mfma(x[:1024], w, auto_max_rows=None)                          # 4 x 9 tiles: the library stays with the K-split kernel
     assert torch.equal(small, pkg.fused.linear_mfma(x[:1024], w, tile_rows=128)) and not torch.equal(small, tile[:1024])
-    if pkg.qtypes.block_geometry(q)[0] == 32:                                                # 32-element-block formats: the auto policy serves up to 128 rows of x (round 6)
-        with pytest.raises(pkg.dequant.GGQUnsupported):
-            pkg.fused.linear_mfma(x[:200], w)
-        assert torch.equal(pkg.fused.linear_mfma(x[:100], w), pkg.fused.linear_mfma(x[:100], w, tile_rows=64))
-    else:
-        assert torch.equal(pkg.fused.linear_mfma(x[:200], w), pkg.fused.linear_mfma(x[:200], w, tile_rows=64))   # <= 256 rows: served by default
+    assert torch.equal(pkg.fused.linear_mfma(x[:200], w), pkg.fused.linear_mfma(x[:200], w, tile_rows=64))       # <= 256 rows on a small weight: served by default, every format
     # an output view that is not 16-byte aligned cannot take the shared-tile epilogue's vector stores: the C entry point says so
     import ctypes
     L = pkg._native.lib()
@@ -174,7 +176,7 @@ def test_exact_arithmetic_cases_are_bit_equal(pkg, name, kind):
     assert np.all(w64 * 2.0 ** 8 == np.round(w64 * 2.0 ** 8)) and np.abs(w64).max() < 64       # every weight a multiple of 2^-8
     g = torch.Generator(device=DEV).manual_seed(3)
     mfma16 = lambda t: (lambda x, w: pkg.fused.linear_mfma(x, w, tile_rows=t))
-    forced = lambda x, w: pkg.fused.linear_mfma(x, w, auto_max_rows=None)        # (the auto policy declines 32-element-block formats above 128 rows of x)
+    forced = lambda x, w: pkg.fused.linear_mfma(x, w, auto_max_rows=None)        # (whatever the auto policy thinks of 160 rows)
     for m, fn in ((37, pkg.fused.linear_mfma), (3, pkg.fused.linear_small), (160, forced), (1, mfma16(16)), (13, mfma16(16)), (29, mfma16(16)),
                   (5, mfma16(0)), (12, mfma16(0))):
         x = torch.randint(-4, 5, (m, cols), device=DEV, generator=g).to(dtype)
