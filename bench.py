@@ -1046,7 +1046,13 @@ def run_fused(pkg, args, device):
             nbytes = sum(packed_of[i] for i in taken)
             flops = sum(2.0 * m * manifest[i][2][0] * manifest[i][2][1] for i in taken)
             gbs = nbytes / (ms_pass * 1e-3) / 1e9
-            kernels = sorted({("ggq::linear_small" if m <= pkg.fused.MAX_ROWS and manifest[i][2][1] <= 6144 else "ggq::linear_mfma16" if m <= 32 else "ggq::linear_mfma") for i in taken})
+            def kernel_of(i):                                    # which kernel fused.linear_auto + the library's own choice end up in ("Policy")
+                rows_w, cols_w = manifest[i][2]
+                bs, ts = pkg.qtypes.block_geometry(manifest[i][1])
+                if m == 1 and rows_w < pkg.fused.SMALL_M_TALL_ROWS and cols_w // bs * ts + 15 <= 6 * 64 * 16:
+                    return "ggq::linear_small"
+                return "ggq::linear_mfma16" if m <= 8 or (m <= 16 and rows_w <= 4096) else "ggq::linear_mfma"
+            kernels = sorted({kernel_of(i) for i in taken})
             out[group][f"m={m}"] = {
                 "layers_fused": len(taken), "layers_declined": len(declined), "declined_shapes": sorted({"x".join(map(str, manifest[i][2])) for i in declined}),
                 "ms_per_pass": round(ms_pass, 4), "us_per_layer": round(ms_pass * 1e3 / max(1, len(taken)), 2), "regions_ms": [round(r, 4) for r in regs],

@@ -147,7 +147,7 @@ def token_table(ts, src):
 
 
 def fused_error_block(fe, src):
-    s = fe["summary"]
+    s = fe.get("summary") or fe["config"]["summary"]          # tools/fused_error.py's own output, or the bench line of `bench.py --workload fused-error`
     kernels = {}
     for c in fe["cases"]:
         if c.get("fused"):
@@ -159,7 +159,7 @@ def fused_error_block(fe, src):
             dec.setdefault(f"{c['qtype']} {c['rows']}×{c['cols']}", set()).add(c["m"])
     declined = "; ".join(f"{k} at {'/'.join(str(m) for m in sorted(v))} rows" for k, v in sorted(dec.items())) or "none"
     return "\n".join([
-        f"Source: `{src}` (`tools/fused_error.py`, {fe.get('device', 'MI355X')}, torch {fe.get('torch', '?')}): {s['cases']} cases = every distinct linear shape of FLUX.1-dev / SD3.5-large / T5-xxl × "
+        f"Source: `{src}` (`bench.py --workload fused-error` = `tools/fused_error.py`, MI355X): {s['cases']} cases = every distinct linear shape of FLUX.1-dev / SD3.5-large / T5-xxl × "
         f"{{1, 4, 64, 256}} rows × {{bf16, fp16}}, error against an fp64 product on the ORACLE's weights, relative to RMS(exact).",
         f"- fused kernel ran in {s['fused_ran']} cases ({by_kernel}); the other {s['declined']} are declined by the auto policy and keep unpack + `F.linear`, which is faster there: {declined};",
         f"- worst RMS-error ratio fused ÷ default: **{s['worst_rms_ratio_fused_over_default']:.7f}**; worst max-error ratio: **{s['worst_max_ratio_fused_over_default']:.4f}**; "

@@ -6,7 +6,10 @@
                                 [--shapes 12288x3072,...] [--reps 5]
 
 One JSON line per (shape, m) on stderr as it goes, the whole table on stdout.  `packed_GBps` = packed bytes of one weight / time:
-the roofline these kernels are priced against is the packed-read rate (8 TB/s spec), DESIGN.md section 4d."""
+the roofline these kernels are priced against is the packed-read rate (8 TB/s spec), DESIGN.md section 4d.
+
+Run it over EVERY format before closing a round (lab/sessions/r6r.sh): the Q4_K-only sweeps of rounds 2-6 could not see Q3_K's 16-way LDS bank conflict, Q5_0's 4-way one
+or Q8_0's register spills (EXPERIMENTS.md R6-9), and SQ_LDS_BANK_CONFLICT reads 0 on this pool."""
 import argparse
 import json
 import os
