@@ -31,6 +31,9 @@
 
 #include "ggq_linear.hpp"
 
+#ifndef GGQ_MF_ABLATE
+#define GGQ_MF_ABLATE 0      /* A/B builds only (WRONG results): 1 = no decode (the MFMA eats raw LDS bytes), 2 = no global loads of x, 4 = (64+ rows of x) no LDS staging of x either */
+#endif
 #ifndef GGQ_MF_SETPRIO
 #define GGQ_MF_SETPRIO 0     /* s_setprio 1 around the MFMAs of a k-step: 4-20 % SLOWER here (1-4 MFMAs per toggle; EXPERIMENTS A2c), unlike the shared-tile kernel; A/B builds */
 #endif
@@ -105,6 +108,9 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
 {
     // partial_ != nullptr: K is ALSO split across workgroups (gridDim.z slices of whole spans, round 6): this workgroup contracts its slice only and stores its fp32
     // partial sums to partial_[blockIdx.z][m][n_rows]; splitk_reduce adds the slices in order, the bias, and casts -- deterministic, like the in-workgroup sum.
+    // (Adding the slices in the last workgroup of each tile instead -- ticket counters, one launch -- was built and ran 6-9x SLOWER, presumably the device-scope release /
+    // acquire it needs on a part with eight L2s; and requesting a span's x fragments BEFORE the next span's weight prefetch, so that the in-order memory pipe does not make
+    // them wait for it, 10-45 % slower than this order: EXPERIMENTS.md R6-11, profiles/r06_mfma32_ablations.json.)
     using G = MfmaGeom<F>;
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
     constexpr int CPB = F::BS / 8;                                                 // chunks per block
@@ -158,10 +164,14 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
 
     // one k-step: decode chunk j of the span (8 weights of row r) and run it against the MB fragments of x
     auto step = [&](const uint8_t* wspan, int j, const u32x4 (&xa)[MB]) {
+#if GGQ_MF_ABLATE & 1
+        const u32x4 wb = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(wspan) & ~(uintptr_t)15) + (j % (G::U - 1)) * 16);
+#else
         const Fields f = F::template fields<true>(wspan + (j / CPB) * F::TS, j % CPB);
         uint32_t w[4];
         weights8<F, OUT>(f, w);
         const u32x4 wb{w[0], w[1], w[2], w[3]};
+#endif
 #if GGQ_MF_SETPRIO
         __builtin_amdgcn_s_setprio(1);             // A/B builds: a wave with MFMAs to issue outranks the ones that decode
 #endif
@@ -199,7 +209,13 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
                 if ((uint32_t)(q * 64) >= len) break;                              // a short last span (wave-uniform)
                 u32x4 xq[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) xq[s4] = *(GGQ_GLOBAL const u32x4*)(xrow + kbyte + (uint32_t)(q * 128 + s4 * 16));
+                for (int s4 = 0; s4 < 4; s4++) {
+#if GGQ_MF_ABLATE & 2
+                    xq[s4] = u32x4{(uint32_t)lane, span, (uint32_t)q, (uint32_t)s4};
+#else
+                    xq[s4] = *(GGQ_GLOBAL const u32x4*)(xrow + kbyte + (uint32_t)(q * 128 + s4 * 16));
+#endif
+                }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
                     const u32x4 xa[MB] = {xq[s4]};
@@ -226,7 +242,13 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
             // the wave's p-th piece: span = first + kw (p / 8), t = p % 8
             const uint32_t kb = ((first + kw * (piece >> 3)) * (uint32_t)(MF_SPAN * 2)) + (piece & 7u) * 64u;
 #pragma unroll
-            for (int i = 0; i < NX; i++) dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
+            for (int i = 0; i < NX; i++) {
+#if GGQ_MF_ABLATE & 2
+                dst[i] = u32x4{(uint32_t)lane, kb, (uint32_t)i, piece};
+#else
+                dst[i] = *(GGQ_GLOBAL const u32x4*)(xsrc[i] + kb);
+#endif
+            }
         };
         const uint32_t my_spans = (first < hi) ? (hi - first + kw - 1) / kw : 0u;
         // 8 pieces of 32 elements per span; the wave that owns the LAST span has fewer in it when that span is short
@@ -246,16 +268,24 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
 #pragma unroll
             for (int t = 0; t < 8; t++, piece++) {                                 // 32 contraction elements per t: k = 32 t + 16 h + 8 s .. + 7
                 if ((uint32_t)(t * 32) >= len) break;                              // a short last span (wave-uniform; it is the wave's last one)
+#if !(GGQ_MF_ABLATE & 4)
 #pragma unroll
                 for (int i = 0; i < NX; i++) *reinterpret_cast<u32x4*>(xs + xdst[i]) = ring[t & 1][i];
                 wave_sync();
+#endif
                 if (piece + 2 < my_pieces) xfetch(piece + 2, ring[t & 1]);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
                     u32x4 xa[MB];
                     const uint32_t col = (((uint32_t)(2 * h + s2)) ^ swr) * 16u;
 #pragma unroll
-                    for (int mb = 0; mb < MB; mb++) xa[mb] = *reinterpret_cast<const u32x4*>(xs + (mb * 32 + r) * MF_XPITCH + col);
+                    for (int mb = 0; mb < MB; mb++) {
+#if GGQ_MF_ABLATE & 4
+                        xa[mb] = u32x4{ring[t & 1][mb].x, col, (uint32_t)lane, piece};
+#else
+                        xa[mb] = *reinterpret_cast<const u32x4*>(xs + (mb * 32 + r) * MF_XPITCH + col);
+#endif
+                    }
                     step(wspan, 4 * t + 2 * h + s2, xa);
                 }
                 wave_sync();                                                       // xs is rewritten at the top of the t loop
