@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(_HERE, "_lib")
 # GGQ_HIP_LIB: load another build of the library (A/B measurements); default = the in-tree build
 LIB_PATH = os.environ.get("GGQ_HIP_LIB") or os.path.join(LIB_DIR, "libggq_hip.so")
 SOURCES = [os.path.join(CSRC, "ggq_capi.hip"), os.path.join(CSRC, "ggq_gguf.hip"), os.path.join(CSRC, "ggq_linear.hip"), os.path.join(CSRC, "ggq_overlap.hip")]
-HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
+HEADERS = [os.path.join(CSRC, "ggq_device.hpp"), os.path.join(CSRC, "ggq_linear.hpp"), os.path.join(CSRC, "ggq_mfma.hpp"), os.path.join(CSRC, "ggq_mfma16.hpp"), os.path.join(CSRC, "ggq_gemm.hpp"), os.path.join(CSRC, "ggq_host.hpp"), os.path.join(ROOT, "include", "ggq.h"), os.path.join(ROOT, "include", "ggq_gguf.h")]
 ABI_VERSION = 11
 
 # -ffp-contract=off is REQUIRED for parity: hipcc otherwise fuses the reference's separately
@@ -141,6 +141,19 @@ def check_no_fma(asm_text):
                              "the reference rounds after every op -- build with -ffp-contract=off")
 
 
+_SPILL_RE = re.compile(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)")
+MAX_SCRATCH_BYTES = 16
+
+
+def check_no_spills(asm_text, limit=MAX_SCRATCH_BYTES):
+    """Raise if a kernel keeps more than ``limit`` bytes per lane in scratch memory (build-time guard, round 6): a register spill is a vector-memory access in front of the
+    in-order weight stream -- the 16-row fused kernel ran Q8_0 at half speed for most of round 6 with 72-108 bytes of it and nothing said so (EXPERIMENTS.md R6-9)."""
+    bad = sorted((int(n), name) for name, n in _SPILL_RE.findall(asm_text) if int(n) > limit)
+    if bad:
+        raise GGQNativeError(f"register spills in {len(bad)} kernels (bytes of scratch per lane, mangled name): {bad[:6]}; lower the instantiation's occupancy request or "
+                             "its widest workgroup (csrc/ggq_mfma16.hpp Mf16Occ, csrc/ggq_mfma.hpp mf_max_waves)")
+
+
 def build(force=False, verbose=False):
     """Compile the HIP extension for gfx950 into comfyui-gguf_amd/_lib/ (cross-compiles without a GPU)."""
     global _lib
@@ -174,7 +187,9 @@ def build(force=False, verbose=False):
             raise GGQNativeError("build produced no gfx950 assembly to check for FMA contraction")
         for f in asm:
             with open(f) as fh:
-                check_no_fma(fh.read())
+                text = fh.read()
+            check_no_fma(text)
+            check_no_spills(text)
         link = [hipcc_path()] + HIPCC_FLAGS + ["-o", out] + [os.path.join(d, os.path.basename(d) + ".o") for _, d, _ in jobs]
         proc = subprocess.run(link, cwd=tmp, capture_output=True, text=True)
         if verbose or proc.returncode:

@@ -109,6 +109,15 @@ def test_fma_guard_regex(pkg):
             nat.check_no_fma(bad)
 
 
+def test_spill_guard(pkg):
+    """The build refuses kernels that keep more than a few bytes per lane in scratch memory (round 6: the 16-row fused kernel spilled 72-108 bytes for Q8_0 and ran at half speed)."""
+    nat = pkg._native
+    meta = "amdhsa.kernels:\n  - .args: []\n    .name:           {name}\n    .private_segment_fixed_size: {n}\n    .sgpr_count:     40\n    .vgpr_count:     96\n"
+    nat.check_no_spills(meta.format(name="_Zfine", n=0) + meta.format(name="_Zalmost", n=nat.MAX_SCRATCH_BYTES))
+    with pytest.raises(nat.GGQNativeError, match="_Zspills"):
+        nat.check_no_spills(meta.format(name="_Zfine", n=0) + meta.format(name="_Zspills", n=72))
+
+
 class _Carrier:
     """Anything with .data/.tensor_type/.tensor_shape is what dequantize_tensor reads (dequant.py:16-17)."""
 
