@@ -108,8 +108,8 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
 {
     // partial_ != nullptr: K is ALSO split across workgroups (gridDim.z slices of whole spans, round 6): this workgroup contracts its slice only and stores its fp32
     // partial sums to partial_[blockIdx.z][m][n_rows]; splitk_reduce adds the slices in order, the bias, and casts -- deterministic, like the in-workgroup sum.
-    // (Adding the slices in the last workgroup of each tile instead -- ticket counters, one launch -- was built and ran 6-9x SLOWER, presumably the device-scope release /
-    // acquire it needs on a part with eight L2s; and requesting a span's x fragments BEFORE the next span's weight prefetch, so that the in-order memory pipe does not make
+    // (Adding the slices in the last workgroup of each tile instead -- ticket counters, one launch -- was built twice: with device-scope fences it ran 6-9x SLOWER (an L2
+    // write-back + invalidate per workgroup on a part with eight L2s); fence-free, through device-scope relaxed atomics, it is correct and level with this.  And requesting a span's x fragments BEFORE the next span's weight prefetch, so that the in-order memory pipe does not make
     // them wait for it, 10-45 % slower than this order: EXPERIMENTS.md R6-11, profiles/r06_mfma32_ablations.json.)
     using G = MfmaGeom<F>;
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
