@@ -34,6 +34,9 @@
 #ifndef GGQ_MF_ABLATE
 #define GGQ_MF_ABLATE 0      /* A/B builds only (WRONG results): 1 = no decode (the MFMA eats raw LDS bytes), 2 = no global loads of x, 4 = (64+ rows of x) no LDS staging of x either */
 #endif
+#ifndef GGQ_MF_XLDS_MIN_MB
+#define GGQ_MF_XLDS_MIN_MB 2   /* blocks of 32 rows of x from which a wave stages its pieces of x through LDS (coalesced 64-byte loads) instead of loading fragments straight from global memory */
+#endif
 #ifndef GGQ_MF_SETPRIO
 #define GGQ_MF_SETPRIO 0     /* s_setprio 1 around the MFMAs of a k-step: 4-20 % SLOWER here (1-4 MFMAs per toggle; EXPERIMENTS A2c), unlike the shared-tile kernel; A/B builds */
 #endif
@@ -97,7 +100,7 @@ GGQ_DEV uint32_t mf_swz(uint32_t row) { return (row >> 3) & 3u; }
 // (16 registers x 64 lanes x 4 B) per wave for the reduction after it
 template <class F, int MB> constexpr uint32_t mf_lds_bytes(uint32_t kw)
 {
-    const uint32_t per_wave = (uint32_t)MfmaGeom<F>::SLICE + (MB >= 2 ? (uint32_t)(MB * 32 * 64) : 0u), red = 16u * 64u * 4u;
+    const uint32_t per_wave = (uint32_t)MfmaGeom<F>::SLICE + (MB >= GGQ_MF_XLDS_MIN_MB ? (uint32_t)(MB * 32 * 64) : 0u), red = 16u * 64u * 4u;
     return kw * (per_wave > red ? per_wave : red);
 }
 
@@ -115,10 +118,10 @@ __global__ __launch_bounds__(mf_max_waves(MB) * 64) void linear_mfma(const uint8
     static_assert(OUT == OUT_F16 || OUT == OUT_BF16, "16-bit activations only (an fp32 MFMA runs at 1/16 of the rate)");
     constexpr int CPB = F::BS / 8;                                                 // chunks per block
     constexpr int RED = 16 * 64 * 4;                                               // one accumulator block of one wave, bytes
-    constexpr bool XLDS = MB >= 2;
+    constexpr bool XLDS = MB >= GGQ_MF_XLDS_MIN_MB;
     constexpr int XS = XLDS ? MB * 32 * MF_XPITCH : 0;                             // LDS bytes per wave for its piece of x
     constexpr int PER_WAVE = G::SLICE + XS;
-    static_assert(RED == 16 * 64 * 4 && (MB < 2 || XS == MB * 32 * 64), "mf_lds_bytes() restates these");
+    static_assert(RED == 16 * 64 * 4 && (!XLDS || XS == MB * 32 * 64), "mf_lds_bytes() restates these");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];                 // mf_lds_bytes<F, MB>(kw)
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
